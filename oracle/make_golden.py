@@ -1,0 +1,299 @@
+"""Generate tests/golden/*.npz by importing the REFERENCE from /root/reference.
+
+Run in the build container only (the reference never travels to the GPU box):
+    python oracle/make_golden.py
+It (1) builds the reference FCMF / FCMFSeq2Seq / BertAdam with the deterministic synthetic
+weights of oracle/synth.py, (2) runs them on synthetic batches with dropout disabled
+(eval mode), (3) checks oracle/fcmf_oracle.py against the reference outputs (<=1e-5, the
+"pin"), and (4) stores the REFERENCE's outputs as small fixtures.  Fixtures hold data only
+(inputs are regenerated from seeds; outputs are arrays) -- no reference source text.
+"""
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+warnings.filterwarnings("ignore")
+
+from oracle import fcmf_oracle as O  # noqa: E402
+from oracle import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def patch_constants(cfg):
+    import fcmf_framework.mm_modeling as mm
+    import fcmf_framework.fcmf_pretraining as fp
+    import fcmf_framework.fcmf_multimodal as fm
+    for mod in (mm, fp, fm):
+        mod.HIDDEN_SIZE = cfg["hidden_size"]
+        mod.NUM_HIDDEN_LAYERS = cfg["num_hidden_layers"]
+        mod.NUM_ATTENTION_HEADS = cfg["num_attention_heads"]
+        mod.INTERMEDIATE_SIZE = cfg["intermediate_size"]
+
+
+def make_hf_dir(cfg):
+    from transformers import RobertaConfig, RobertaModel
+    c = RobertaConfig(**{k: v for k, v in cfg.items()})
+    d = tempfile.mkdtemp(prefix="hf_")
+    RobertaModel(c).save_pretrained(d)
+    return d
+
+
+def load_synth_into(model, shapes, seed=0):
+    sd = model.state_dict()
+    P = synth.synth_params(shapes, seed)
+    missing = [k for k in P if k not in sd]
+    assert not missing, missing[:5]
+    for k, v in P.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+    extra = [k for k in sd if k not in P and "position_ids" not in k and "token_type_ids" not in k]
+    model.load_state_dict(P, strict=False)
+    return P, extra
+
+
+def run_reference_fcmf(model, batch, num_aspects):
+    crit = torch.nn.CrossEntropyLoss()
+    total = 0
+    logits = []
+    for a in range(num_aspects):
+        lg = model(input_ids=batch["input_ids"][:, a], token_type_ids=batch["token_type_ids"][:, a],
+                   attention_mask=batch["attention_mask"][:, a],
+                   added_attention_mask=batch["added_attention_mask"][:, a],
+                   visual_embeds_att=batch["visual_embeds_att"], roi_embeds_att=batch["roi_embeds_att"],
+                   roi_coors=batch["roi_coors"])
+        total = total + crit(lg, batch["labels"][:, a])
+        logits.append(lg)
+    return total, torch.stack(logits, 1)
+
+
+def reference_param_groups(model, lr_enc=7e-5, lr_head=7e-4):
+    # mirrors the driver's grouping so that torch.optim.AdamW runs exactly as in the reference loop
+    no_decay = ['bias', 'LayerNorm.bias', 'LayerNorm.weight']
+    head_names = ['classifier', 'text_pooler']
+    enc, head = [], []
+    for n, p in model.named_parameters():
+        (head if any(h in n for h in head_names) else enc).append((n, p))
+    return [
+        {'params': [p for n, p in enc if not any(nd in n for nd in no_decay)], 'weight_decay': 0.01, 'lr': lr_enc},
+        {'params': [p for n, p in enc if any(nd in n for nd in no_decay)], 'weight_decay': 0.0, 'lr': lr_enc},
+        {'params': [p for n, p in head if not any(nd in n for nd in no_decay)], 'weight_decay': 0.01, 'lr': lr_head},
+        {'params': [p for n, p in head if any(nd in n for nd in no_decay)], 'weight_decay': 0.0, 'lr': lr_head},
+    ]
+
+
+def fcmf_fixture(tag, cfg, B, S, NI, NR, store_all_grads):
+    from transformers import get_linear_schedule_with_warmup
+    patch_constants(cfg)
+    from fcmf_framework.fcmf_multimodal import FCMF
+    hf = make_hf_dir(cfg)
+    model = FCMF(hf, num_labels=4, num_imgs=NI, num_roi=NR)
+    shapes = synth.fcmf_param_shapes(cfg)
+    P, extra = load_synth_into(model, shapes)
+    print(tag, "params", sum(p.numel() for p in model.parameters()), "unmapped keys:", extra)
+    model.eval()
+    batch = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, seed=42)
+
+    # intermediates for aspect 0 via the oracle's collect hook AND reference forward hooks
+    ref_inter = {}
+    def keep(key, pick):
+        def hook(m, i, o):
+            ref_inter.setdefault(key, pick(o).detach())
+            return None  # a non-None return would replace the module output
+        return hook
+    hooks = [
+        model.encoder.bert.register_forward_hook(keep("sequence_output", lambda o: o[0])),
+        model.encoder.box_head.register_forward_hook(keep("rel0", lambda o: o)),
+        model.encoder.text2img_attention.register_forward_hook(keep("t2i0", lambda o: o[-1])),
+        model.encoder.mm_attention.register_forward_hook(keep("mm0", lambda o: o[-1])),
+    ]
+    model.zero_grad()
+    loss, logits = run_reference_fcmf(model, batch, 6)
+    for h in hooks:
+        h.remove()
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    nograd = [n for n, p in model.named_parameters() if p.grad is None]
+    print(tag, "loss", float(loss), "no-grad params:", nograd)
+
+    # ---- oracle pin -------------------------------------------------------------------
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    o_loss, o_logits = O.fcmf_step_loss(Pg, cfg, batch, NI, NR, training=False)
+    o_loss.backward()
+    err_logits = (o_logits - logits).abs().max().item()
+    err_loss = abs(float(o_loss) - float(loss))
+    gerr = 0.0
+    for n, g in grads.items():
+        og = Pg[n].grad
+        if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias"):
+            continue  # key.bias grads are analytically zero (softmax shift invariance): rounding noise only
+        e = (og - g).abs().max().item() / (g.abs().max().item() + 1e-20)
+        if e > 1e-4:
+            print("   grad mismatch", n, e, g.abs().max().item())
+        gerr = max(gerr, e)
+    col = {}
+    O.fcmf_forward(P, cfg, batch["input_ids"][:, 0], batch["visual_embeds_att"], batch["roi_embeds_att"],
+                   batch["roi_coors"], batch["token_type_ids"][:, 0], batch["attention_mask"][:, 0],
+                   batch["added_attention_mask"][:, 0], NI, NR, collect=col)
+    ierr = {k: (col[k] - ref_inter[k]).abs().max().item() for k in ref_inter}
+    print(tag, f"oracle-vs-reference: logits {err_logits:.2e} loss {err_loss:.2e} grads(rel) {gerr:.2e} inter {ierr}")
+    assert err_logits < 1e-5 and err_loss < 1e-5 and gerr < 1e-4, "oracle does not reproduce the reference"
+    assert all(v < 1e-4 for v in ierr.values())
+
+    # ---- reference clip + AdamW + scheduler step (run_multimodal_fcmf.py:485-488) -------
+    opt = torch.optim.AdamW(reference_param_groups(model), lr=7e-4)
+    sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=10, num_training_steps=100)
+    sched.step()  # leave the lr=0 first step so that the update is visible (factor 1/10)
+    total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt.step()
+    after = {n: p.detach().clone() for n, p in model.named_parameters()}
+
+    out = dict(logits=logits.detach().numpy(), loss=np.float32(loss.item()),
+               total_grad_norm=np.float32(float(total_norm)),
+               B=B, S=S, NI=NI, NR=NR)
+    names = sorted(grads)
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array([grads[n].norm().item() for n in names], dtype=np.float64)
+    out["nograd_names"] = np.array(nograd)
+    out["delta_norms"] = np.array([(after[n] - before[n]).norm().item() for n in names], dtype=np.float64)
+    rng = np.random.Generator(np.random.PCG64(7))
+    for k, v in ref_inter.items():
+        out["inter_" + k] = v.numpy() if v.numel() < 40000 else v.flatten()[:: max(1, v.numel() // 4096)].numpy()
+    sample_names = names if store_all_grads else [
+        "classifier.weight", "text_pooler.dense.bias",
+        "encoder.mm_attention.layer.0.attention.self.key.weight",
+        "encoder.mm_attention.layer.0.output.LayerNorm.weight",
+        "encoder.text2img_attention.layer.0.attention.self.query.weight",
+        "encoder.text2img_attention.layer.0.intermediate.dense.bias",
+        "encoder.box_head.WGs.3.weight", "encoder.box_head.WGs.3.bias", "encoder.box_head.linears.0.weight",
+        "encoder.vismap2text.weight", "encoder.roimap2text.bias",
+        f"encoder.bert.cell.encoder.layer.{cfg['num_hidden_layers'] - 1}.output.dense.weight",
+        "encoder.bert.cell.encoder.layer.0.attention.self.value.weight",
+        "encoder.bert.cell.embeddings.word_embeddings.weight",
+        "encoder.bert.cell.embeddings.position_embeddings.weight",
+        "encoder.bert.cell.embeddings.LayerNorm.weight"]
+    for n in sample_names:
+        g = grads[n].flatten()
+        d = (after[n] - before[n]).flatten()
+        if g.numel() > 2048:
+            idx = np.sort(rng.choice(g.numel(), size=2048, replace=False))
+            out["gidx_" + n] = idx
+            out["g_" + n] = g[idx].numpy()
+            out["d_" + n] = d[idx].numpy()
+        else:
+            out["g_" + n] = g.numpy()
+            out["d_" + n] = d.numpy()
+    np.savez_compressed(os.path.join(GOLD, f"fcmf_{tag}.npz"), **out)
+    print(tag, "written", os.path.getsize(os.path.join(GOLD, f"fcmf_{tag}.npz")) // 1024, "KiB")
+
+
+def box_fixture():
+    patch_constants(synth.BASE_CFG)
+    from fcmf_framework.roi_modeling import BoxMultiHeadedAttention
+    m = BoxMultiHeadedAttention(8, 768).eval()
+    rng = np.random.Generator(np.random.PCG64(3))
+    xs = np.sort(rng.random((2, 6, 2)), -1)
+    ys = np.sort(rng.random((2, 6, 2)), -1)
+    c = np.concatenate([xs, ys], -1)
+    c[1, 4:] = 0.0  # zero-padded boxes
+    c64 = torch.from_numpy(c)
+    e64 = m.BoxRelationalEmbedding(c64)
+    e32 = m.BoxRelationalEmbedding(c64.float())
+    o64 = O.box_relational_embedding(c64)
+    o32 = O.box_relational_embedding(c64.float())
+    assert (e64 - o64).abs().max() < 1e-9 and (e32 - o32).abs().max() < 1e-5
+    np.savez_compressed(os.path.join(GOLD, "box_embedding.npz"), coords=c, emb64=e64.numpy(), emb32=e32.numpy())
+    print("box fixture ok", tuple(e64.shape))
+
+
+def bertadam_fixture():
+    from fcmf_framework.optimization import BertAdam, warmup_linear, warmup_constant
+    rng = np.random.Generator(np.random.PCG64(11))
+    p0 = torch.from_numpy(rng.standard_normal((5, 7)).astype(np.float32))
+    gs = [torch.from_numpy((rng.standard_normal((5, 7)) * s).astype(np.float32)) for s in (3.0, 0.1, 1.0)]
+    p = torch.nn.Parameter(p0.clone())
+    opt = BertAdam([p], lr=1e-2, warmup=0.1, t_total=20, weight_decay=0.01)
+    traj = []
+    lrs = []
+    for g in gs:
+        p.grad = g.clone()
+        opt.step()
+        traj.append(p.detach().clone().numpy())
+        lrs.append(opt.get_lr()[0])
+    # oracle pin
+    q, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for i, g in enumerate(gs):
+        q, m, v = O.bertadam_update(q, g, m, v, i, 1e-2, 0.01, t_total=20, warmup=0.1)
+        assert (q - torch.from_numpy(traj[i])).abs().max() < 1e-6
+    xs = np.array([0.0, 0.001, 0.002, 0.05, 0.5, 0.99])
+    np.savez_compressed(os.path.join(GOLD, "bertadam.npz"), p0=p0.numpy(), grads=np.stack([g.numpy() for g in gs]),
+                        traj=np.stack(traj), lrs=np.array(lrs, dtype=np.float64), xs=xs,
+                        warmup_linear=np.array([warmup_linear(x) for x in xs]),
+                        warmup_constant=np.array([warmup_constant(x) for x in xs]))
+    print("bertadam fixture ok")
+
+
+def iaog_fixture():
+    cfg = synth.TINY_CFG
+    patch_constants(cfg)
+    from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq
+    hf = make_hf_dir(cfg)
+    V = cfg["vocab_size"]
+    NI, NR, B, S, Ld = 2, 5, 3, 16, 6
+    model = FCMFSeq2Seq(V, 20, hf, NI, NR, 1.0)
+    # run_pretraining_fcmf.py:189 -- decoder.embedding is re-created (un-tied) by the driver
+    model.decoder.embedding = torch.nn.Embedding(V, model.decoder.num_hiddens)
+    shapes = synth.fcmf_param_shapes(cfg)
+    shapes = {k: v for k, v in shapes.items() if k.startswith("encoder.")}
+    shapes.update(synth.iaog_decoder_param_shapes(cfg, V))
+    P, extra = load_synth_into(model, shapes)
+    print("iaog unmapped keys:", extra)
+    model.eval()
+    batch = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, seed=5, coord_dtype=torch.float32)
+    rng = np.random.Generator(np.random.PCG64(9))
+    dec = torch.from_numpy(rng.integers(3, V, size=(B, Ld)))
+    labels = torch.roll(dec, -1, dims=1).clone()
+    labels[:, -1] = -100
+    logits = model(batch["input_ids"][:, 0], dec, batch["visual_embeds_att"], batch["roi_embeds_att"],
+                   batch["roi_coors"], batch["token_type_ids"][:, 0], batch["attention_mask"][:, 0],
+                   batch["added_attention_mask"][:, 0], None, is_train=True)
+    loss = torch.nn.CrossEntropyLoss(ignore_index=-100)(logits.permute(0, 2, 1), labels)
+    cross_w = model.decoder.blks.block0.attention2.attention_weights.detach()
+    # oracle pin
+    Pw = dict(P)
+    Pw["decoder.dense.weight"] = P["encoder.bert.cell.embeddings.word_embeddings.weight"]
+    enc = O.fcmf_encoder_forward(Pw, cfg, batch["input_ids"][:, 0], batch["visual_embeds_att"],
+                                 batch["roi_embeds_att"], batch["roi_coors"], batch["token_type_ids"][:, 0],
+                                 batch["attention_mask"][:, 0], batch["added_attention_mask"][:, 0], NI, NR)
+    ol = O.iaog_decoder_forward(Pw, cfg, dec, enc)
+    err = (ol - logits).abs().max().item()
+    print("iaog oracle-vs-reference logits", err, "loss", float(loss))
+    assert err < 1e-4
+    np.savez_compressed(os.path.join(GOLD, "iaog_tiny.npz"), dec=dec.numpy(), labels=labels.numpy(),
+                        logits=logits.detach().numpy()[:, :, ::8], loss=np.float32(loss.item()),
+                        cross_attn_nonzero=(cross_w[0] > 1e-30).sum(-1).numpy())
+    print("iaog fixture ok")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["box", "bertadam", "tiny", "iaog", "base"]
+    if "box" in which:
+        box_fixture()
+    if "bertadam" in which:
+        bertadam_fixture()
+    if "tiny" in which:
+        fcmf_fixture("tiny", synth.TINY_CFG, B=3, S=16, NI=2, NR=5, store_all_grads=False)
+    if "iaog" in which:
+        iaog_fixture()
+    if "base" in which:
+        fcmf_fixture("base", synth.BASE_CFG, B=2, S=128, NI=7, NR=36, store_all_grads=False)
