@@ -1,0 +1,224 @@
+/* fcmf_hip.h -- C ABI of libfcmf_hip.so: the MI355X (gfx950) kernels underneath the
+ * `fcmf_framework` Python module surface.
+ *
+ * The reference (sonbui25/Multimodal-Aspect-Category-Sentiment-Analysis) has no FFI layer:
+ * its operators are whatever torch dispatches from fcmf_framework/{mm_modeling,roi_modeling,
+ * fcmf_pretraining,fcmf_multimodal,optimization}.py.  Each entry point below names the
+ * reference code (file:line under /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *    synchronises, nothing allocates (workspaces are caller-provided);
+ *  - return value: 0 = FCMF_OK, negative = error (no exceptions cross the ABI);
+ *  - dtype codes select the ACTIVATION storage type; master parameters, optimizer state,
+ *    LayerNorm statistics, logsumexp and gradients of parameters are always float32.
+ */
+#ifndef FCMF_HIP_H
+#define FCMF_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCMF_OK 0
+#define FCMF_ERR_ARG (-1)
+#define FCMF_ERR_LAUNCH (-2)
+#define FCMF_ERR_UNSUPPORTED (-3)
+
+#define FCMF_F32 0
+#define FCMF_BF16 1
+#define FCMF_F64 2
+
+/* GEMM epilogues */
+#define FCMF_EPI_NONE 0   /* C = acc + bias                                            */
+#define FCMF_EPI_GELU 1   /* C = gelu_erf(acc + bias); aux (if non-NULL) <- acc + bias  */
+#define FCMF_EPI_TANH 2   /* C = tanh(acc + bias)                                       */
+#define FCMF_EPI_DGELU 3  /* C = acc * gelu'(aux)      (aux = saved pre-activation)     */
+#define FCMF_EPI_DTANH 4  /* C = acc * (1 - aux^2)     (aux = saved tanh output)        */
+
+int fcmf_abi_version(void);
+/* human-readable "gfx950 ..." build string (host pointer, static storage) */
+const char* fcmf_build_info(void);
+
+/* ---------------------------------------------------------------------------------------
+ * GEMM:  C[M,N] (+)= epilogue( op(A)[M,K] * op(B)[K,N] + bias[N] )
+ *   trans_a = 0: A stored [M,K] (row stride lda)      trans_a = 1: A stored [K,M]
+ *   trans_b = 0: B stored [N,K] (nn.Linear weight)    trans_b = 1: B stored [K,N]
+ *   in_dtype: dtype of A and B; out_dtype: dtype of C and aux; bias is float32 or NULL.
+ *   accumulate != 0 (out_dtype must be F32): C += result (split-K partials are added
+ *   with float atomics, so C must be initialised).
+ * Replaces nn.Linear forward/backward everywhere on the path: mm_modeling.py:182-184,
+ * 229-231,272,308,320,422 ; fcmf_pretraining.py:25-26 ; roi_modeling.py:73 ;
+ * fcmf_multimodal.py:18 and their autograd (dX = dY*W, dW = dY^T*X).
+ * bf16 inputs whose contiguous dimensions are multiples of 8 elements with 16-byte aligned
+ * bases run on the MFMA bf16 kernel; everything else runs on the generic f32-MFMA kernel. */
+int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux,
+              int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+              int trans_a, int trans_b, int in_dtype, int out_dtype,
+              int epilogue, int accumulate, void* stream);
+
+/* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X dtype = dtype, out float32. */
+int fcmf_colsum(const void* X, float* out, int M, int N, int64_t ldx, int dtype,
+                int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Two-segment multi-head attention (VALU, any dtype).  One "group" g has R query rows; every
+ * row attends to T1 keys shared by the group (K1/V1) followed by T2 keys private to the row
+ * (K2/V2, indexed by g / group_div so that several groups can share the private segment).
+ *   score[t] = scale * <q, k_t> + mask[g, t] + bias[g / group_div, h, r, t]
+ *   causal != 0: score[t] = -1e4 where t > r   (IAOG `Attention`, mm_modeling.py:115-124)
+ *   p = dropout(softmax(score)); out = sum_t p[t] v_t ; lse[g,h,r] = logsumexp(score)
+ * Layouts (elements): Q  (g,r,h,:) at q  + g*q_sg  + r*q_sr  + h*d
+ *                     K1 (g,t,h,:) at k1 + g*k1_sg + t*k1_st + h*d          (V1 same strides)
+ *                     K2 (g2,r,t,h,:) at k2 + g2*k2_sg + r*k2_sr + t*k2_st + h*d  (V2 same)
+ *                     O  (g,r,h,:) at o  + g*o_sg  + r*o_sr  + h*d          (dO same)
+ * head_quirk != 0 reproduces mm_modeling.py:79-85: output slot h of group g READS Q/K/V head
+ * (h*G + g) % heads; the backward WRITES dq/dk/dv at slot h (several slots may read one head, so
+ * the caller scatter-adds slots back to heads).
+ * Replaces BertSelfAttention/BertCoAttention (mm_modeling.py:193-219,240-266), HF
+ * eager_attention_forward, box_attention (roi_modeling.py:14-47) and Attention
+ * (mm_modeling.py:66-132). */
+typedef struct {
+  int dtype, G, heads, d, R, T1, T2, group_div;
+  int64_t q_sg, q_sr, k1_sg, k1_st, k2_sg, k2_sr, k2_st, o_sg, o_sr;
+  const void *q, *k1, *v1, *k2, *v2;
+  const float* mask;   /* [G, T1+T2] additive or NULL */
+  const float* bias;   /* [G/group_div, heads, R, T1+T2] additive or NULL */
+  float scale, dropout_p;
+  uint64_t seed;
+  int causal, head_quirk;
+} fcmf_attn_desc;
+
+int fcmf_attn_small_fwd(const fcmf_attn_desc* desc /*host*/, void* out, float* lse, void* stream);
+/* Gradients are written DENSE (independent of the input strides) and fully overwritten:
+ *   dq  [ceil(T1/128) or 1, G, R, heads*d] -- one partial per 128-key chunk of the shared segment;
+ *       the caller sums the leading axis (fcmf_sum_axis);
+ *   dk1/dv1 [G, T1, heads*d];   dk2/dv2 [G, R, T2, heads*d] (indexed by g, NOT g/group_div: the
+ *       caller sums groups that share a private segment);
+ *   dbias (float32, may be NULL) [G, heads, R, T1+T2].
+ * When v1 == k1 (IAOG) pass dv1 = NULL: dk1 receives both terms.  Limits: T1+T2 <= 256, T2 <= 128,
+ * d <= 128. */
+int fcmf_attn_small_bwd(const fcmf_attn_desc* desc /*host*/, const void* out, const void* dout,
+                        const float* lse, void* dq, void* dk1, void* dv1, void* dk2, void* dv2,
+                        float* dbias, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MFMA self/cross attention for bf16, head dim 64, Tk <= 128 (the text-encoder layers):
+ *   Q [G,Tq,heads*64], K/V [G,Tk,heads*64] (row strides ldq/ldk elements), mask [G,Tk] additive.
+ * Replaces HF RobertaSelfAttention + eager_attention_forward and mm_modeling.py:193-219. */
+int fcmf_attn_mfma_fwd(const void* q, const void* k, const void* v, const float* mask,
+                       void* out, float* lse, int G, int heads, int Tq, int Tk,
+                       int64_t ldq, int64_t ldk, int64_t ldo, float scale,
+                       float dropout_p, uint64_t seed, void* stream);
+int fcmf_attn_mfma_bwd(const void* q, const void* k, const void* v, const float* mask,
+                       const void* out, const void* dout, const float* lse,
+                       void* dq, void* dk, void* dv, int G, int heads, int Tq, int Tk,
+                       int64_t ldq, int64_t ldk, int64_t ldo, float scale,
+                       float dropout_p, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * y = LayerNorm(dropout(x) + res) * gamma + beta   (eps inside the sqrt, biased variance)
+ * Replaces BertSelfOutput/BertOutput/AddNorm + FCMFLayerNorm (mm_modeling.py:158-171,
+ * 276-280,324-328,566-573) and HF nn.LayerNorm(eps=1e-5).
+ *   x [rows,H] dense; res row r at res + r*res_stride (NULL = no residual);
+ *   z (optional, may alias x) <- dropout(x)+res ; mean/rstd float32 [rows]. */
+int fcmf_add_ln_fwd(const void* x, const void* res, int64_t res_stride, const float* gamma,
+                    const float* beta, void* y, void* z, float* mean, float* rstd,
+                    int rows, int H, float eps, float dropout_p, uint64_t seed, int dtype,
+                    void* stream);
+/* dz [rows,H] <- grad wrt (dropout(x)+res); dx (NULL when dropout_p==0: dx == dz) <- grad wrt x;
+ * dgamma/dbeta float32 [H] are ACCUMULATED (atomics). */
+int fcmf_add_ln_bwd(const void* dy, const void* z, const float* gamma, const float* mean,
+                    const float* rstd, void* dz, void* dx, float* dgamma, float* dbeta,
+                    int rows, int H, float dropout_p, uint64_t seed, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * RoBERTa embeddings (HF RobertaEmbeddings via mm_modeling.py:440-446).
+ * position ids = cumsum(ids != pad) * (ids != pad) + pad, one sequence per wave. */
+int fcmf_position_ids(const int64_t* ids, int64_t* pos, int nseq, int S, int pad_id, void* stream);
+/* z = word[ids] + pos_table[pos] + type[type_ids] (tables float32), then LayerNorm as above. */
+int fcmf_embed_ln_fwd(const int64_t* ids, const int64_t* pos, const int64_t* type_ids,
+                      const float* word, const float* pos_table, const float* type_table,
+                      const float* gamma, const float* beta, void* y, void* z, float* mean,
+                      float* rstd, int ntok, int H, float eps, float dropout_p, uint64_t seed,
+                      int dtype, void* stream);
+/* scatter-add dz into the float32 table gradients (pad rows of word/pos receive nothing). */
+int fcmf_embed_bwd(const void* dz, const int64_t* ids, const int64_t* pos, const int64_t* type_ids,
+                   float* dword, float* dpos, float* dtype_table, int ntok, int H, int pad_id,
+                   int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Box geometry (roi_modeling.py:79-138,161-163 and the log-clamp of :40), fused:
+ *   bias[g,h,i,j] = log(max(relu(<WG_h, emb(box_i, box_j)> + b_h), 1e-6))
+ * coords [G,N,4] = (x_min,x_max,y_min,y_max) in float64 or float32 (coord_dtype);
+ * wg_w [heads,64], wg_b [heads] float32 (heads <= 8); bias float32 [G,heads,N,N];
+ * dim_mat: device float32[8] = 1/1000^(k/8) as the reference rounds it (roi_modeling.py:123-125). */
+int fcmf_box_bias_fwd(const void* coords, int coord_dtype, const float* dim_mat, const float* wg_w,
+                      const float* wg_b, float* bias, int G, int N, int heads, void* stream);
+/* dwg_w/dwg_b are ACCUMULATED. */
+int fcmf_box_bias_bwd(const void* coords, int coord_dtype, const float* dim_mat, const float* wg_w,
+                      const float* wg_b, const float* dbias, float* dwg_w, float* dwg_b, int G, int N,
+                      int heads, void* stream);
+/* the raw 64-d relational embedding [G,N,N,64] float32 (tests / API parity of
+ * BoxMultiHeadedAttention.BoxRelationalEmbedding). */
+int fcmf_box_embedding(const void* coords, int coord_dtype, const float* dim_mat, float* emb, int G,
+                       int N, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Cross entropy over C classes (run_multimodal_fcmf.py:290,474; ignore_index for IAOG
+ * run_pretraining_fcmf.py:322-324).  loss_rows[n] = -log softmax(logits[n])[label] (0 if ignored);
+ * nvalid <- number of non-ignored rows (float). */
+int fcmf_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, float* loss_rows,
+                  float* nvalid, int n, int C, int64_t ignore_index, int dtype, void* stream);
+/* dlogits[n,c] = (softmax - onehot) * (*scale_ptr) * extra_scale  (0 for ignored rows) */
+int fcmf_xent_bwd(const void* logits, int64_t ld, const int64_t* labels, void* dlogits,
+                  int64_t ldd, const float* scale_ptr, float extra_scale, int n, int C,
+                  int64_t ignore_index, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * elementwise helpers */
+int fcmf_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* y = x * dropout_mask(seed) / (1-p) ; used for the classifier-head dropout
+ * (fcmf_multimodal.py:49) and its backward (same call on dy). */
+int fcmf_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* out = dy * act'(aux): kind 0 = tanh (aux = tanh OUTPUT, BertPooler mm_modeling.py:430),
+ * kind 1 = erf-GELU (aux = PRE-activation, mm_modeling.py:15). */
+int fcmf_act_bwd(const void* dy, const void* aux, void* out, int64_t n, int kind, int dtype,
+                 void* stream);
+/* out[i] (+)= sum over the `reps` copies: in is [outer, reps, inner] -> out [outer, inner] */
+int fcmf_sum_axis(const void* in, void* out, int64_t outer, int reps, int64_t inner, int dtype,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimizer (run_multimodal_fcmf.py:485-488: clip_grad_norm_ + torch.optim.AdamW, 4 groups).
+ * Tensors are described by device tables: ptr tables are int64 device arrays of device
+ * addresses; `chunk_tensor[c]`/`chunk_offset[c]` assign chunk c (chunk_size elements) to a
+ * tensor and a start offset. */
+int fcmf_multi_sumsq(const int64_t* g_ptrs, const int64_t* sizes, const int32_t* chunk_tensor,
+                     const int64_t* chunk_offset, int nchunks, int chunk_size,
+                     double* sumsq /* [1], accumulated */, double* per_tensor /* [ntensors] or NULL */,
+                     void* stream);
+/* AdamW with decoupled weight decay, bias correction, eps outside sqrt(v_hat) (torch
+ * semantics).  The clip coefficient min(1, max_norm/(sqrt(*sumsq)+1e-6)) is computed on
+ * device (max_norm <= 0 disables).  group_of[t] selects lr[]/wd[] (host arrays, <= 8 groups).
+ * bf16_ptrs (may be NULL; entries may be 0): shadow bf16 copies refreshed after the update. */
+int fcmf_multi_adamw(const int64_t* p_ptrs, const int64_t* g_ptrs, const int64_t* m_ptrs,
+                     const int64_t* v_ptrs, const int64_t* bf16_ptrs, const int64_t* sizes,
+                     const int32_t* group_of, const int32_t* chunk_tensor,
+                     const int64_t* chunk_offset, int nchunks, int chunk_size,
+                     const float* lr /*host[8]*/, const float* wd /*host[8]*/, int ngroups,
+                     float beta1, float beta2, float eps, int step, const double* sumsq,
+                     float max_norm, void* stream);
+/* BertAdam.step for one tensor (optimization.py:94-162): per-parameter clip, no bias
+ * correction, weight decay added to the update; `lr_scheduled` is computed by the host
+ * from the warmup schedule. `scratch` is a device double[1]. */
+int fcmf_bertadam(float* p, const float* g, float* m, float* v, int64_t n, float lr_scheduled,
+                  float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                  double* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCMF_HIP_H */

@@ -1,0 +1,187 @@
+// Geometry bias of the ROI relation attention, fused so that the [G,N,N,64] relational embedding
+// is never materialised (roi_modeling.py:79-138 BoxRelationalEmbedding, :161-163 eight Linear(64,1)
+// + ReLU, :40 log(clamp(.,1e-6))).  The embedding is evaluated in the dtype of the box
+// coordinates (float64 in the fine-tune loop, float32 in IAOG), then rounded to float32 before the
+// WG dot products, exactly as the reference does (roi_modeling.py:150).
+#include "common.h"
+
+template <typename CT> struct Trig;
+template <> struct Trig<double> {
+  static __device__ __forceinline__ void sc(double x, double* s, double* c) { sincos(x, s, c); }
+  static __device__ __forceinline__ double lg(double x) { return log(x); }
+  static __device__ __forceinline__ double ab(double x) { return fabs(x); }
+  static __device__ __forceinline__ double mx(double a, double b) { return fmax(a, b); }
+};
+template <> struct Trig<float> {
+  static __device__ __forceinline__ void sc(float x, float* s, float* c) { sincosf(x, s, c); }
+  static __device__ __forceinline__ float lg(float x) { return logf(x); }
+  static __device__ __forceinline__ float ab(float x) { return fabsf(x); }
+  static __device__ __forceinline__ float mx(float a, float b) { return fmaxf(a, b); }
+};
+
+// emb[0..31] = sin(100 * delta_c * dim_mat[k]), emb[32..63] = cos(...), index c*8+k (:128-135)
+template <typename CT>
+__device__ __forceinline__ void box_embed(const CT* __restrict__ coords, const float* __restrict__ dim_mat, int64_t g,
+                                          int N, int i, int j, float (&emb)[64]) {
+  const CT* bi = coords + (g * N + i) * 4;
+  const CT* bj = coords + (g * N + j) * 4;
+  const CT cxi = (bi[0] + bi[1]) * (CT)0.5, cyi = (bi[2] + bi[3]) * (CT)0.5;
+  const CT wi = (bi[1] - bi[0]) + (CT)1, hi = (bi[3] - bi[2]) + (CT)1;
+  const CT cxj = (bj[0] + bj[1]) * (CT)0.5, cyj = (bj[2] + bj[3]) * (CT)0.5;
+  const CT wj = (bj[1] - bj[0]) + (CT)1, hj = (bj[3] - bj[2]) + (CT)1;
+  CT dl[4];
+  dl[0] = Trig<CT>::lg(Trig<CT>::mx(Trig<CT>::ab((cxi - cxj) / wi), (CT)1e-3));
+  dl[1] = Trig<CT>::lg(Trig<CT>::mx(Trig<CT>::ab((cyi - cyj) / hi), (CT)1e-3));
+  dl[2] = Trig<CT>::lg(wi / wj);
+  dl[3] = Trig<CT>::lg(hi / hj);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const CT base = (CT)100 * dl[c];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      CT s, co;
+      Trig<CT>::sc(base * (CT)dim_mat[k], &s, &co);
+      emb[c * 8 + k] = (float)s;
+      emb[32 + c * 8 + k] = (float)co;
+    }
+  }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void box_bias_fwd_kernel(const CT* __restrict__ coords, const float* __restrict__ dim_mat,
+                                                           const float* __restrict__ wg_w, const float* __restrict__ wg_b,
+                                                           float* __restrict__ bias, float* __restrict__ emb_out,
+                                                           int G, int N, int heads) {
+  __shared__ float w[16 * 64 + 16];
+  for (int e = threadIdx.x; e < heads * 64 + heads; e += 256)
+    w[e] = wg_w ? (e < heads * 64 ? wg_w[e] : wg_b[e - heads * 64]) : 0.f;
+  __syncthreads();
+  const int64_t total = (int64_t)G * N * N;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t g = idx / (N * N);
+    const int rem = (int)(idx - g * N * N);
+    const int i = rem / N, j = rem - i * N;
+    float emb[64];
+    box_embed<CT>(coords, dim_mat, g, N, i, j, emb);
+    if (emb_out) {
+#pragma unroll
+      for (int e = 0; e < 64; ++e) emb_out[idx * 64 + e] = emb[e];
+    }
+    if (bias) {
+      for (int h = 0; h < heads; ++h) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 64; ++e) acc += emb[e] * w[h * 64 + e];
+        acc += w[heads * 64 + h];
+        const float v = fmaxf(acc, 0.f);
+        bias[((g * heads + h) * N + i) * N + j] = logf(fmaxf(v, 1e-6f));
+      }
+    }
+  }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void box_bias_bwd_kernel(const CT* __restrict__ coords, const float* __restrict__ dim_mat,
+                                                           const float* __restrict__ wg_w, const float* __restrict__ wg_b,
+                                                           const float* __restrict__ dbias, float* __restrict__ dwg_w,
+                                                           float* __restrict__ dwg_b, int G, int N, int heads) {
+  // per iteration the block stages 256 embeddings E[256][65] and pre-activation grads D[256][8];
+  // each thread then owns two (head, e) entries of the 8x64 (+bias column) outer-product sum.
+  __shared__ float w[8 * 64 + 8];
+  __shared__ float E[256][65];
+  __shared__ float D[256][9];
+  for (int e = threadIdx.x; e < heads * 64 + heads; e += 256) w[e] = e < heads * 64 ? wg_w[e] : wg_b[e - heads * 64];
+  __syncthreads();
+  const int64_t total = (int64_t)G * N * N;
+  const int tid = threadIdx.x;
+  // outputs owned: o0 = tid, o1 = tid + 256 over the heads*64 weight entries; thread < heads also owns db[tid]
+  float a0 = 0.f, a1 = 0.f, ab = 0.f;
+  const int h0 = tid >> 6, e0 = tid & 63, h1 = (tid + 256) >> 6, e1 = e0;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {
+    const int64_t idx = base + tid;
+    if (idx < total) {
+      const int64_t g = idx / (N * N);
+      const int rem = (int)(idx - g * N * N);
+      const int i = rem / N, j = rem - i * N;
+      float emb[64];
+      box_embed<CT>(coords, dim_mat, g, N, i, j, emb);
+#pragma unroll
+      for (int e = 0; e < 64; ++e) E[tid][e] = emb[e];
+      for (int h = 0; h < heads; ++h) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 64; ++e) acc += emb[e] * w[h * 64 + e];
+        acc += w[heads * 64 + h];
+        const float db = dbias[((g * heads + h) * N + i) * N + j];
+        // d log(max(relu(x),1e-6)) / dx = 1/x where x > 1e-6, else 0
+        D[tid][h] = acc > 1e-6f ? db / acc : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 64; ++e) E[tid][e] = 0.f;
+      for (int h = 0; h < heads; ++h) D[tid][h] = 0.f;
+    }
+    __syncthreads();
+    for (int r = 0; r < 256; ++r) {
+      const float er = E[r][e0];
+      if (h0 < heads) a0 += D[r][h0] * er;
+      if (h1 < heads) a1 += D[r][h1] * er;
+    }
+    if (tid < heads)
+      for (int r = 0; r < 256; ++r) ab += D[r][tid];
+    __syncthreads();
+  }
+  if (h0 < heads) atomicAdd(dwg_w + h0 * 64 + e0, a0);
+  if (h1 < heads) atomicAdd(dwg_w + h1 * 64 + e1, a1);
+  if (tid < heads) atomicAdd(dwg_b + tid, ab);
+}
+
+static int box_grid(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" int fcmf_box_bias_fwd(const void* coords, int coord_dtype, const float* dim_mat, const float* wg_w,
+                                 const float* wg_b, float* bias, int G, int N, int heads, void* stream) {
+  if (!coords || !dim_mat || !wg_w || !wg_b || !bias || G <= 0 || N <= 0 || heads <= 0 || heads > 8) return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(box_grid((int64_t)G * N * N));
+  if (coord_dtype == FCMF_F64)
+    hipLaunchKernelGGL((box_bias_fwd_kernel<double>), grid, dim3(256), 0, st, (const double*)coords, dim_mat, wg_w, wg_b, bias, (float*)nullptr, G, N, heads);
+  else if (coord_dtype == FCMF_F32)
+    hipLaunchKernelGGL((box_bias_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)coords, dim_mat, wg_w, wg_b, bias, (float*)nullptr, G, N, heads);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_box_embedding(const void* coords, int coord_dtype, const float* dim_mat, float* emb, int G, int N,
+                                  void* stream) {
+  if (!coords || !dim_mat || !emb || G <= 0 || N <= 0) return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(box_grid((int64_t)G * N * N));
+  if (coord_dtype == FCMF_F64)
+    hipLaunchKernelGGL((box_bias_fwd_kernel<double>), grid, dim3(256), 0, st, (const double*)coords, dim_mat, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, emb, G, N, 0);
+  else if (coord_dtype == FCMF_F32)
+    hipLaunchKernelGGL((box_bias_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)coords, dim_mat, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, emb, G, N, 0);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_box_bias_bwd(const void* coords, int coord_dtype, const float* dim_mat, const float* wg_w,
+                                 const float* wg_b, const float* dbias, float* dwg_w, float* dwg_b, int G, int N,
+                                 int heads, void* stream) {
+  if (!coords || !dim_mat || !wg_w || !wg_b || !dbias || !dwg_w || !dwg_b || G <= 0 || N <= 0 || heads <= 0 || heads > 8)
+    return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int64_t b = ((int64_t)G * N * N + 255) / 256;
+  dim3 grid((int)(b > 512 ? 512 : b));
+  if (coord_dtype == FCMF_F64)
+    hipLaunchKernelGGL((box_bias_bwd_kernel<double>), grid, dim3(256), 0, st, (const double*)coords, dim_mat, wg_w, wg_b, dbias, dwg_w, dwg_b, G, N, heads);
+  else if (coord_dtype == FCMF_F32)
+    hipLaunchKernelGGL((box_bias_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)coords, dim_mat, wg_w, wg_b, dbias, dwg_w, dwg_b, G, N, heads);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}

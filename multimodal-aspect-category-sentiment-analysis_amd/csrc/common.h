@@ -1,0 +1,84 @@
+// Shared device helpers for the FCMF gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fcmf_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FCMF_CHECK_LAUNCH()                                            \
+  do {                                                                 \
+    hipError_t e__ = hipGetLastError();                                \
+    if (e__ != hipSuccess) return FCMF_ERR_LAUNCH;                     \
+  } while (0)
+
+// ---- scalar conversions ----------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// 4-wide vector load/store of T as float4 (T = float: 16 B, T = bf16: 8 B)
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void store(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct Vec4<bf16_t> {
+  static __device__ __forceinline__ float4 load(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, float4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+};
+
+// ---- wave / block reductions (wave = 64 lanes) --------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- counter-based dropout RNG --------------------------------------------------------------
+// Stateless hash of (seed, element index): forward and backward regenerate the same mask
+// without storing it.  murmur3-style finaliser over a 64-bit counter folded with the seed.
+__device__ __forceinline__ uint32_t fcmf_hash(uint64_t seed, uint64_t idx) {
+  uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (uint32_t)x;
+}
+// returns the multiplier applied to the element: 0 (dropped) or 1/(1-p) (kept)
+__device__ __forceinline__ float dropout_mult(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+  float u = (float)(fcmf_hash(seed, idx) >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+// exact-erf GELU and its derivative (mm_modeling.py:10-15)
+__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}

@@ -1,0 +1,328 @@
+// Cross entropy, casts, dropout, axis sums and the fused clip + AdamW / BertAdam updates.
+// All of these are HBM-bound streaming kernels: 16-byte accesses, grid-stride, no re-reads.
+#include "common.h"
+
+// ---- cross entropy: one wave per row, classes strided over lanes --------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void xent_fwd_kernel(const T* __restrict__ logits, int64_t ld,
+                                                       const int64_t* __restrict__ labels, float* __restrict__ loss_rows,
+                                                       float* __restrict__ nvalid, int n, int C, int64_t ignore_index) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t lab = labels[row];
+  if (lab == ignore_index) { if (lane == 0) loss_rows[row] = 0.f; return; }
+  const T* lr = logits + (int64_t)row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, to_f32<T>(lr[c]));
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(to_f32<T>(lr[c]) - m);
+  s = wave_sum(s);
+  if (lane == 0) {
+    loss_rows[row] = (m + __logf(s)) - to_f32<T>(lr[lab]);
+    if (nvalid) atomicAdd(nvalid, 1.0f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xent_bwd_kernel(const T* __restrict__ logits, int64_t ld,
+                                                       const int64_t* __restrict__ labels, T* __restrict__ dlogits,
+                                                       int64_t ldd, const float* __restrict__ scale_ptr, float extra,
+                                                       int n, int C, int64_t ignore_index) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t lab = labels[row];
+  T* dr = dlogits + (int64_t)row * ldd;
+  if (lab == ignore_index) { for (int c = lane; c < C; c += 64) dr[c] = from_f32<T>(0.f); return; }
+  const T* lr = logits + (int64_t)row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, to_f32<T>(lr[c]));
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(to_f32<T>(lr[c]) - m);
+  s = wave_sum(s);
+  const float sc = (scale_ptr ? *scale_ptr : 1.0f) * extra;
+  for (int c = lane; c < C; c += 64) {
+    float pr = __expf(to_f32<T>(lr[c]) - m) / s;
+    dr[c] = from_f32<T>((pr - (c == lab ? 1.f : 0.f)) * sc);
+  }
+}
+
+// ---- elementwise ---------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    Vec4<TD>::store(d + i * 4, Vec4<TS>::load(s + i * 4));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) d[n4 * 4 + threadIdx.x] = from_f32<TD>(to_f32<TS>(s[n4 * 4 + threadIdx.x]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p,
+                                                      float inv_keep, uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = from_f32<T>(to_f32<T>(x[i]) * dropout_mult(seed, (uint64_t)i, p, inv_keep));
+}
+
+// out = dy * act'(aux): kind 0 = tanh (aux = tanh output), kind 1 = gelu (aux = pre-activation)
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ aux, T* __restrict__ out,
+                                                      int64_t n, int kind) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = to_f32<T>(aux[i]), d = to_f32<T>(dy[i]);
+    out[i] = from_f32<T>(kind == 0 ? d * (1.0f - a * a) : d * dgelu_f(a));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sum_axis_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t outer,
+                                                       int reps, int64_t inner) {
+  const int64_t total = outer * inner;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t o = i / inner, c = i - o * inner;
+    float s = 0.f;
+    for (int r = 0; r < reps; ++r) s += to_f32<T>(in[(o * reps + r) * inner + c]);
+    out[i] = from_f32<T>(s);
+  }
+}
+
+// ---- optimizer ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void multi_sumsq_kernel(const int64_t* __restrict__ g_ptrs, const int64_t* __restrict__ sizes,
+                                                          const int32_t* __restrict__ chunk_tensor,
+                                                          const int64_t* __restrict__ chunk_offset, int chunk_size,
+                                                          double* __restrict__ sumsq, double* __restrict__ per_tensor) {
+  __shared__ double red[4];
+  const int t = chunk_tensor[blockIdx.x];
+  const int64_t off = chunk_offset[blockIdx.x];
+  const float* g = reinterpret_cast<const float*>(g_ptrs[t]) + off;
+  int64_t n = sizes[t] - off;
+  if (n > chunk_size) n = chunk_size;
+  double s = 0.0;
+  const bool vec = (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i * 4);
+      s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += (double)g[i] * g[i];
+  } else {
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)g[i] * g[i];
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = red[0] + red[1] + red[2] + red[3];
+    if (sumsq) atomicAdd(sumsq, tot);
+    if (per_tensor) atomicAdd(per_tensor + t, tot);
+  }
+}
+
+struct AdamArgs {
+  const int64_t *p_ptrs, *g_ptrs, *m_ptrs, *v_ptrs, *bf16_ptrs, *sizes;
+  const int32_t *group_of, *chunk_tensor;
+  const int64_t* chunk_offset;
+  int chunk_size;
+  float lr[8], wd[8];
+  float beta1, beta2, eps, bc1, bc2_sqrt;
+  const double* sumsq;
+  float max_norm;
+};
+
+__global__ __launch_bounds__(256) void multi_adamw_kernel(AdamArgs a) {
+  const int t = a.chunk_tensor[blockIdx.x];
+  const int64_t off = a.chunk_offset[blockIdx.x];
+  float* p = reinterpret_cast<float*>(a.p_ptrs[t]) + off;
+  const float* g = reinterpret_cast<const float*>(a.g_ptrs[t]) + off;
+  float* m = reinterpret_cast<float*>(a.m_ptrs[t]) + off;
+  float* v = reinterpret_cast<float*>(a.v_ptrs[t]) + off;
+  bf16_t* sh = a.bf16_ptrs && a.bf16_ptrs[t] ? reinterpret_cast<bf16_t*>(a.bf16_ptrs[t]) + off : nullptr;
+  int64_t n = a.sizes[t] - off;
+  if (n > a.chunk_size) n = a.chunk_size;
+  const int grp = a.group_of[t];
+  const float lr = a.lr[grp], wd = a.wd[grp];
+  float coef = 1.0f;
+  if (a.max_norm > 0.f && a.sumsq) {
+    const float tn = (float)sqrt(*a.sumsq);
+    coef = fminf(1.0f, a.max_norm / (tn + 1e-6f));
+  }
+  const float step_size = lr / a.bc1;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = a.beta1 * m[i] + (1.0f - a.beta1) * gi;
+    const float vi = a.beta2 * v[i] + (1.0f - a.beta2) * gi * gi;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (sh) sh[i] = (bf16_t)pi;
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)g[i] * g[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, int64_t n, float lr, float b1, float b2, float e,
+                                                       float wd, float max_norm, const double* __restrict__ sumsq) {
+  float coef = 1.0f;
+  if (max_norm > 0.f) coef = fminf(1.0f, max_norm / ((float)sqrt(*sumsq) + 1e-6f));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    float upd = mi / (sqrtf(vi) + e);
+    if (wd > 0.f) upd += wd * p[i];
+    p[i] -= lr * upd;
+    m[i] = mi; v[i] = vi;
+  }
+}
+
+// ---- host ----------------------------------------------------------------------------------
+static int grid_for(int64_t n, int per) {
+  int64_t b = (n + per - 1) / per;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+extern "C" int fcmf_abi_version(void) { return 1; }
+extern "C" const char* fcmf_build_info(void) { return "libfcmf_hip gfx950 (CDNA4, wave64) abi 1"; }
+
+extern "C" int fcmf_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, float* loss_rows, float* nvalid, int n,
+                             int C, int64_t ignore_index, int dtype, void* stream) {
+  if (!logits || !labels || !loss_rows || n < 0 || C <= 0) return FCMF_ERR_ARG;
+  if (n == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((n + 3) / 4);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((xent_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)logits, ld, labels, loss_rows, nvalid, n, C, ignore_index);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((xent_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)logits, ld, labels, loss_rows, nvalid, n, C, ignore_index);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_xent_bwd(const void* logits, int64_t ld, const int64_t* labels, void* dlogits, int64_t ldd,
+                             const float* scale_ptr, float extra_scale, int n, int C, int64_t ignore_index, int dtype,
+                             void* stream) {
+  if (!logits || !labels || !dlogits || n < 0 || C <= 0) return FCMF_ERR_ARG;
+  if (n == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((n + 3) / 4);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((xent_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)logits, ld, labels, (float*)dlogits, ldd, scale_ptr, extra_scale, n, C, ignore_index);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((xent_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)logits, ld, labels, (bf16_t*)dlogits, ldd, scale_ptr, extra_scale, n, C, ignore_index);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream) {
+  if (!src || !dst || n < 0) return FCMF_ERR_ARG;
+  if (n == 0) return FCMF_OK;
+  if ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 7)) return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(grid_for(n, 1024));
+  if (src_dtype == FCMF_F32 && dst_dtype == FCMF_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == FCMF_BF16 && dst_dtype == FCMF_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == FCMF_F32 && dst_dtype == FCMF_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, n);
+  else if (src_dtype == FCMF_BF16 && dst_dtype == FCMF_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+  if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return FCMF_ERR_ARG;
+  if (n == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(grid_for(n, 256));
+  const float inv_keep = 1.0f / (1.0f - p);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((dropout_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (float*)y, n, p, inv_keep, seed);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n, p, inv_keep, seed);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_act_bwd(const void* dy, const void* aux, void* out, int64_t n, int kind, int dtype, void* stream) {
+  if (!dy || !aux || !out || n < 0 || (kind != 0 && kind != 1)) return FCMF_ERR_ARG;
+  if (n == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(grid_for(n, 256));
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((act_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dy, (const float*)aux, (float*)out, n, kind);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)aux, (bf16_t*)out, n, kind);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_sum_axis(const void* in, void* out, int64_t outer, int reps, int64_t inner, int dtype, void* stream) {
+  if (!in || !out || outer < 0 || reps <= 0 || inner <= 0) return FCMF_ERR_ARG;
+  if (outer == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(grid_for(outer * inner, 256));
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((sum_axis_kernel<float>), grid, dim3(256), 0, st, (const float*)in, (float*)out, outer, reps, inner);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((sum_axis_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, outer, reps, inner);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_multi_sumsq(const int64_t* g_ptrs, const int64_t* sizes, const int32_t* chunk_tensor,
+                                const int64_t* chunk_offset, int nchunks, int chunk_size, double* sumsq,
+                                double* per_tensor, void* stream) {
+  if (!g_ptrs || !sizes || !chunk_tensor || !chunk_offset || nchunks < 0 || chunk_size <= 0) return FCMF_ERR_ARG;
+  if (nchunks == 0) return FCMF_OK;
+  hipLaunchKernelGGL(multi_sumsq_kernel, dim3(nchunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g_ptrs, sizes,
+                     chunk_tensor, chunk_offset, chunk_size, sumsq, per_tensor);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_multi_adamw(const int64_t* p_ptrs, const int64_t* g_ptrs, const int64_t* m_ptrs, const int64_t* v_ptrs,
+                                const int64_t* bf16_ptrs, const int64_t* sizes, const int32_t* group_of,
+                                const int32_t* chunk_tensor, const int64_t* chunk_offset, int nchunks, int chunk_size,
+                                const float* lr, const float* wd, int ngroups, float beta1, float beta2, float eps, int step,
+                                const double* sumsq, float max_norm, void* stream) {
+  if (!p_ptrs || !g_ptrs || !m_ptrs || !v_ptrs || !sizes || !group_of || !chunk_tensor || !chunk_offset || !lr || !wd)
+    return FCMF_ERR_ARG;
+  if (ngroups <= 0 || ngroups > 8 || step < 1 || chunk_size <= 0 || nchunks < 0) return FCMF_ERR_ARG;
+  if (nchunks == 0) return FCMF_OK;
+  AdamArgs a{};
+  a.p_ptrs = p_ptrs; a.g_ptrs = g_ptrs; a.m_ptrs = m_ptrs; a.v_ptrs = v_ptrs; a.bf16_ptrs = bf16_ptrs; a.sizes = sizes;
+  a.group_of = group_of; a.chunk_tensor = chunk_tensor; a.chunk_offset = chunk_offset; a.chunk_size = chunk_size;
+  for (int i = 0; i < ngroups; ++i) { a.lr[i] = lr[i]; a.wd[i] = wd[i]; }
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.sumsq = sumsq; a.max_norm = max_norm;
+  hipLaunchKernelGGL(multi_adamw_kernel, dim3(nchunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_bertadam(float* p, const float* g, float* m, float* v, int64_t n, float lr_scheduled, float beta1,
+                             float beta2, float eps, float weight_decay, float max_grad_norm, double* scratch,
+                             void* stream) {
+  if (!p || !g || !m || !v || n < 0) return FCMF_ERR_ARG;
+  if (max_grad_norm > 0.f && !scratch) return FCMF_ERR_ARG;
+  if (n == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(grid_for(n, 1024));
+  if (max_grad_norm > 0.f) {
+    if (hipMemsetAsync(scratch, 0, sizeof(double), st) != hipSuccess) return FCMF_ERR_LAUNCH;
+    hipLaunchKernelGGL(sumsq_kernel, grid, dim3(256), 0, st, g, n, scratch);
+  }
+  hipLaunchKernelGGL(bertadam_kernel, grid, dim3(256), 0, st, p, g, m, v, n, lr_scheduled, beta1, beta2, eps, weight_decay,
+                     max_grad_norm, scratch);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}

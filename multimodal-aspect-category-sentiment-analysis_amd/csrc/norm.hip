@@ -1,0 +1,379 @@
+// Fused dropout + residual + LayerNorm (TF style: biased variance, eps inside the sqrt) and the
+// RoBERTa embedding gather + LayerNorm.  One wave per row, 4 elements per lane per pass
+// (8-byte bf16 / 16-byte f32 accesses), statistics in f32.  HBM-bound: per row the forward
+// reads x (+res) and writes y (+z); nothing else is materialised.
+#include "common.h"
+
+constexpr int LN_MAXP = 8;  // up to 8 passes of 256 columns: H <= 2048 (NP template = passes)
+
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                         int64_t res_stride, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         T* __restrict__ z, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int rows, int H, float eps,
+                                                         float p, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  float4 v[NP];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      float4 a = Vec4<T>::load(x + (int64_t)row * H + c);
+      if (p > 0.f) {
+        const uint64_t base = (uint64_t)row * H + c;
+        a.x *= dropout_mult(seed, base + 0, p, inv_keep); a.y *= dropout_mult(seed, base + 1, p, inv_keep);
+        a.z *= dropout_mult(seed, base + 2, p, inv_keep); a.w *= dropout_mult(seed, base + 3, p, inv_keep);
+      }
+      if (res) {
+        float4 r = Vec4<T>::load(res + (int64_t)row * res_stride + c);
+        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+      }
+      v[i] = a;
+      s += a.x + a.y + a.z + a.w;
+    }
+  }
+  const float mu = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+      q += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)H + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      if (z) Vec4<T>::store(z + (int64_t)row * H + c, v[i]);
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
+      o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
+      Vec4<T>::store(y + (int64_t)row * H + c, o);
+    }
+  }
+}
+
+// Backward: dz = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)).  dgamma/dbeta are summed
+// over the rows a block walks in registers, across its 4 waves through LDS, then one float
+// atomic per column per block.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, T* __restrict__ dz,
+                                                         T* __restrict__ dx, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int rows, int H, float p,
+                                                         uint64_t seed) {
+  __shared__ float4 red[2][2][NP][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  float4 ag[NP], ab[NP], gm[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
+    const int c = (i * 64 + lane) * 4;
+    gm[i] = c < H ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0, 0, 0, 0);
+  }
+  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 gy[NP], xh[NP];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        const float4 d = Vec4<T>::load(dy + (int64_t)row * H + c);
+        const float4 zz = Vec4<T>::load(z + (int64_t)row * H + c);
+        float4 h; h.x = (zz.x - mu) * rs; h.y = (zz.y - mu) * rs; h.z = (zz.z - mu) * rs; h.w = (zz.w - mu) * rs;
+        ag[i].x += d.x * h.x; ag[i].y += d.y * h.y; ag[i].z += d.z * h.z; ag[i].w += d.w * h.w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        float4 g; g.x = d.x * gm[i].x; g.y = d.y * gm[i].y; g.z = d.z * gm[i].z; g.w = d.w * gm[i].w;
+        gy[i] = g; xh[i] = h;
+        s1 += g.x + g.y + g.z + g.w;
+        s2 += g.x * h.x + g.y * h.y + g.z * h.z + g.w * h.w;
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        float4 o;
+        o.x = rs * (gy[i].x - s1 - xh[i].x * s2); o.y = rs * (gy[i].y - s1 - xh[i].y * s2);
+        o.z = rs * (gy[i].z - s1 - xh[i].z * s2); o.w = rs * (gy[i].w - s1 - xh[i].w * s2);
+        Vec4<T>::store(dz + (int64_t)row * H + c, o);
+        if (dx) {
+          const uint64_t base = (uint64_t)row * H + c;
+          o.x *= dropout_mult(seed, base + 0, p, inv_keep); o.y *= dropout_mult(seed, base + 1, p, inv_keep);
+          o.z *= dropout_mult(seed, base + 2, p, inv_keep); o.w *= dropout_mult(seed, base + 3, p, inv_keep);
+          Vec4<T>::store(dx + (int64_t)row * H + c, o);
+        }
+      }
+    }
+  }
+  // cross-wave reduction: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds; atomics
+#pragma unroll
+  for (int step = 0; step < 2; ++step) {
+    const int half = step == 0 ? 2 : 1;
+    if (w >= half && w < 2 * half) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) { red[w - half][0][i][lane] = ag[i]; red[w - half][1][i][lane] = ab[i]; }
+    }
+    __syncthreads();
+    if (w < half) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        float4 a = red[w][0][i][lane], b = red[w][1][i][lane];
+        ag[i].x += a.x; ag[i].y += a.y; ag[i].z += a.z; ag[i].w += a.w;
+        ab[i].x += b.x; ab[i].y += b.y; ab[i].z += b.z; ab[i].w += b.w;
+      }
+    }
+    __syncthreads();
+  }
+  if (w == 0) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        atomicAdd(dgamma + c + 0, ag[i].x); atomicAdd(dgamma + c + 1, ag[i].y);
+        atomicAdd(dgamma + c + 2, ag[i].z); atomicAdd(dgamma + c + 3, ag[i].w);
+        atomicAdd(dbeta + c + 0, ab[i].x); atomicAdd(dbeta + c + 1, ab[i].y);
+        atomicAdd(dbeta + c + 2, ab[i].z); atomicAdd(dbeta + c + 3, ab[i].w);
+      }
+    }
+  }
+}
+
+// ---- RoBERTa embeddings -----------------------------------------------------------------
+__global__ __launch_bounds__(64) void position_ids_kernel(const int64_t* __restrict__ ids, int64_t* __restrict__ pos,
+                                                          int S, int pad_id) {
+  // one wave per sequence: running count of non-pad tokens via ballot prefix
+  const int lane = threadIdx.x;
+  const int64_t* row = ids + (int64_t)blockIdx.x * S;
+  int64_t* out = pos + (int64_t)blockIdx.x * S;
+  int running = 0;
+  for (int t0 = 0; t0 < S; t0 += 64) {
+    const int t = t0 + lane;
+    const bool nz = t < S && row[t] != pad_id;
+    const unsigned long long b = __ballot(nz);
+    const int incl = __popcll(b & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1)));
+    if (t < S) out[t] = nz ? (int64_t)(running + incl + pad_id) : (int64_t)pad_id;
+    running += __popcll(b);
+  }
+}
+
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos,
+                                                           const int64_t* __restrict__ tt, const float* __restrict__ word,
+                                                           const float* __restrict__ ptab, const float* __restrict__ ttab,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           T* __restrict__ y, T* __restrict__ z, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, int ntok, int H, float eps, float p,
+                                                           uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= ntok) return;
+  const float* wr = word + ids[row] * H;
+  const float* pr = ptab + pos[row] * H;
+  const float* tr = ttab + (tt ? tt[row] : 0) * H;
+  float4 v[NP];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      const float4 a = *reinterpret_cast<const float4*>(wr + c);
+      const float4 b = *reinterpret_cast<const float4*>(tr + c);
+      const float4 d = *reinterpret_cast<const float4*>(pr + c);
+      // same association as HF: (word + type) + position
+      float4 o; o.x = (a.x + b.x) + d.x; o.y = (a.y + b.y) + d.y; o.z = (a.z + b.z) + d.z; o.w = (a.w + b.w) + d.w;
+      v[i] = o;
+      s += o.x + o.y + o.z + o.w;
+    }
+  }
+  const float mu = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+      q += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)H + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      if (z) Vec4<T>::store(z + (int64_t)row * H + c, v[i]);
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
+      o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
+      if (p > 0.f) {  // HF applies dropout AFTER the embedding LayerNorm
+        const uint64_t base = (uint64_t)row * H + c;
+        o.x *= dropout_mult(seed, base + 0, p, inv_keep); o.y *= dropout_mult(seed, base + 1, p, inv_keep);
+        o.z *= dropout_mult(seed, base + 2, p, inv_keep); o.w *= dropout_mult(seed, base + 3, p, inv_keep);
+      }
+      Vec4<T>::store(y + (int64_t)row * H + c, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dz, const int64_t* __restrict__ ids,
+                                                        const int64_t* __restrict__ pos, const int64_t* __restrict__ tt,
+                                                        float* __restrict__ dword, float* __restrict__ dpos,
+                                                        float* __restrict__ dtt, int ntok, int H, int pad_id) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= ntok) return;
+  const int64_t id = ids[row], ps = pos[row], ty = tt ? tt[row] : 0;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 d = Vec4<T>::load(dz + (int64_t)row * H + c);
+    if (id != pad_id) {
+      float* w = dword + id * H + c;
+      atomicAdd(w + 0, d.x); atomicAdd(w + 1, d.y); atomicAdd(w + 2, d.z); atomicAdd(w + 3, d.w);
+    }
+    if (ps != pad_id) {
+      float* q = dpos + ps * H + c;
+      atomicAdd(q + 0, d.x); atomicAdd(q + 1, d.y); atomicAdd(q + 2, d.z); atomicAdd(q + 3, d.w);
+    }
+    if (dtt && ty != 0) {  // type row 0 is summed by a column reduction (every token hits it)
+      float* q = dtt + ty * H + c;
+      atomicAdd(q + 0, d.x); atomicAdd(q + 1, d.y); atomicAdd(q + 2, d.z); atomicAdd(q + 3, d.w);
+    }
+  }
+}
+
+// type-row-0 gradient: column sum over the tokens whose type id is 0
+template <typename T>
+__global__ __launch_bounds__(256) void embed_type0_kernel(const T* __restrict__ dz, const int64_t* __restrict__ tt,
+                                                          float* __restrict__ dtt, int ntok, int H, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(ntok, r0 + rows_per_block);
+  float s = 0.f;
+  if (col < H)
+    for (int r = r0 + w; r < r1; r += 4)
+      if (!tt || tt[r] == 0) s += to_f32<T>(dz[(int64_t)r * H + col]);
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && col < H) atomicAdd(dtt + col, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+// pick the smallest pass count NP (256 columns per pass) that covers H
+#define LN_DISPATCH_T(T, H)                         \
+  do {                                              \
+    const int np__ = ((H) + 255) / 256;             \
+    if (np__ <= 1) LAUNCH_(T, 1);                   \
+    else if (np__ <= 2) LAUNCH_(T, 2);              \
+    else if (np__ <= 3) LAUNCH_(T, 3);              \
+    else if (np__ <= 4) LAUNCH_(T, 4);              \
+    else LAUNCH_(T, 8);                             \
+  } while (0)
+#define LN_DISPATCH(dtype, H)                                     \
+  do {                                                            \
+    if ((dtype) == FCMF_F32) LN_DISPATCH_T(float, H);             \
+    else LN_DISPATCH_T(bf16_t, H);                                \
+  } while (0)
+
+// ---- host ---------------------------------------------------------------------------------
+extern "C" int fcmf_add_ln_fwd(const void* x, const void* res, int64_t res_stride, const float* gamma,
+                               const float* beta, void* y, void* z, float* mean, float* rstd, int rows, int H,
+                               float eps, float dropout_p, uint64_t seed, int dtype, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0 || H <= 0) return FCMF_ERR_ARG;
+  if (H % 4 != 0 || H > LN_MAXP * 256 || (res && res_stride % 4 != 0)) return FCMF_ERR_UNSUPPORTED;
+  if (rows == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((rows + 3) / 4);
+  if (dtype != FCMF_F32 && dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
+#define LAUNCH_(T, NP) hipLaunchKernelGGL((add_ln_fwd_kernel<T, NP>), grid, dim3(256), 0, st, (const T*)x, (const T*)res, \
+    res_stride, gamma, beta, (T*)y, (T*)z, mean, rstd, rows, H, eps, dropout_p, seed)
+  LN_DISPATCH(dtype, H);
+#undef LAUNCH_
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_add_ln_bwd(const void* dy, const void* z, const float* gamma, const float* mean, const float* rstd,
+                               void* dz, void* dx, float* dgamma, float* dbeta, int rows, int H, float dropout_p,
+                               uint64_t seed, int dtype, void* stream) {
+  if (!dy || !z || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || rows < 0 || H <= 0) return FCMF_ERR_ARG;
+  if (H % 4 != 0 || H > LN_MAXP * 256) return FCMF_ERR_UNSUPPORTED;
+  if (dropout_p > 0.f && !dx) return FCMF_ERR_ARG;
+  if (rows == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  if (dtype != FCMF_F32 && dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
+#define LAUNCH_(T, NP) hipLaunchKernelGGL((add_ln_bwd_kernel<T, NP>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)z, \
+    gamma, mean, rstd, (T*)dz, (T*)(dropout_p > 0.f ? dx : nullptr), dgamma, dbeta, rows, H, dropout_p, seed)
+  LN_DISPATCH(dtype, H);
+#undef LAUNCH_
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_position_ids(const int64_t* ids, int64_t* pos, int nseq, int S, int pad_id, void* stream) {
+  if (!ids || !pos || nseq < 0 || S <= 0) return FCMF_ERR_ARG;
+  if (nseq == 0) return FCMF_OK;
+  hipLaunchKernelGGL(position_ids_kernel, dim3(nseq), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ids, pos, S, pad_id);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_embed_ln_fwd(const int64_t* ids, const int64_t* pos, const int64_t* type_ids, const float* word,
+                                 const float* pos_table, const float* type_table, const float* gamma, const float* beta,
+                                 void* y, void* z, float* mean, float* rstd, int ntok, int H, float eps, float dropout_p,
+                                 uint64_t seed, int dtype, void* stream) {
+  if (!ids || !pos || !word || !pos_table || !type_table || !gamma || !beta || !y || !mean || !rstd) return FCMF_ERR_ARG;
+  if (H % 4 != 0 || H > LN_MAXP * 256) return FCMF_ERR_UNSUPPORTED;
+  if (ntok <= 0) return ntok == 0 ? FCMF_OK : FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((ntok + 3) / 4);
+  if (dtype != FCMF_F32 && dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
+#define LAUNCH_(T, NP) hipLaunchKernelGGL((embed_ln_fwd_kernel<T, NP>), grid, dim3(256), 0, st, ids, pos, type_ids, word, \
+    pos_table, type_table, gamma, beta, (T*)y, (T*)z, mean, rstd, ntok, H, eps, dropout_p, seed)
+  LN_DISPATCH(dtype, H);
+#undef LAUNCH_
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_embed_bwd(const void* dz, const int64_t* ids, const int64_t* pos, const int64_t* type_ids, float* dword,
+                              float* dpos, float* dtype_table, int ntok, int H, int pad_id, int dtype, void* stream) {
+  if (!dz || !ids || !pos || !dword || !dpos) return FCMF_ERR_ARG;
+  if (H % 4 != 0) return FCMF_ERR_UNSUPPORTED;
+  if (ntok <= 0) return ntok == 0 ? FCMF_OK : FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((ntok + 3) / 4);
+  const int rpb = 512;
+  dim3 g2((H + 63) / 64, (ntok + rpb - 1) / rpb);
+  if (dtype == FCMF_F32) {
+    hipLaunchKernelGGL((embed_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dz, ids, pos, type_ids, dword, dpos, dtype_table, ntok, H, pad_id);
+    if (dtype_table) hipLaunchKernelGGL((embed_type0_kernel<float>), g2, dim3(256), 0, st, (const float*)dz, type_ids, dtype_table, ntok, H, rpb);
+  } else if (dtype == FCMF_BF16) {
+    hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dz, ids, pos, type_ids, dword, dpos, dtype_table, ntok, H, pad_id);
+    if (dtype_table) hipLaunchKernelGGL((embed_type0_kernel<bf16_t>), g2, dim3(256), 0, st, (const bf16_t*)dz, type_ids, dtype_table, ntok, H, rpb);
+  } else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}

@@ -1,0 +1,120 @@
+"""ctypes binding of libfcmf_hip.so (C ABI declared in include/fcmf_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails the
+product raises.  (The CPU restatement under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcmf_hip.so")
+
+F32, BF16, F64 = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_TANH, EPI_DGELU, EPI_DTANH = 0, 1, 2, 3, 4
+
+_c = ctypes
+_vp, _i, _i64, _f, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
+
+
+class AttnDesc(ctypes.Structure):
+    """mirror of fcmf_attn_desc"""
+    _fields_ = [
+        ("dtype", _i), ("G", _i), ("heads", _i), ("d", _i), ("R", _i), ("T1", _i), ("T2", _i), ("group_div", _i),
+        ("q_sg", _i64), ("q_sr", _i64), ("k1_sg", _i64), ("k1_st", _i64), ("k2_sg", _i64), ("k2_sr", _i64),
+        ("k2_st", _i64), ("o_sg", _i64), ("o_sr", _i64),
+        ("q", _vp), ("k1", _vp), ("v1", _vp), ("k2", _vp), ("v2", _vp),
+        ("mask", _vp), ("bias", _vp),
+        ("scale", _f), ("dropout_p", _f), ("seed", _u64), ("causal", _i), ("head_quirk", _i),
+    ]
+
+
+# name -> argtypes (restype is int unless noted); must list EVERY symbol of include/fcmf_hip.h
+SIGNATURES = {
+    "fcmf_abi_version": [],
+    "fcmf_build_info": [],
+    "fcmf_gemm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_colsum": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
+    "fcmf_attn_small_fwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp],
+    "fcmf_attn_small_bwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fcmf_attn_mfma_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _f, _f, _u64, _vp],
+    "fcmf_attn_mfma_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _f, _f,
+                           _u64, _vp],
+    "fcmf_add_ln_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _i, _vp],
+    "fcmf_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _i, _vp],
+    "fcmf_position_ids": [_vp, _vp, _i, _i, _i, _vp],
+    "fcmf_embed_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _i, _vp],
+    "fcmf_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fcmf_box_bias_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "fcmf_box_bias_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "fcmf_box_embedding": [_vp, _i, _vp, _vp, _i, _i, _vp],
+    "fcmf_xent_fwd": [_vp, _i64, _vp, _vp, _vp, _i, _i, _i64, _i, _vp],
+    "fcmf_xent_bwd": [_vp, _i64, _vp, _vp, _i64, _vp, _f, _i, _i, _i64, _i, _vp],
+    "fcmf_cast": [_vp, _vp, _i64, _i, _i, _vp],
+    "fcmf_dropout": [_vp, _vp, _i64, _f, _u64, _i, _vp],
+    "fcmf_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "fcmf_sum_axis": [_vp, _vp, _i64, _i, _i64, _i, _vp],
+    "fcmf_multi_sumsq": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "fcmf_multi_adamw": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _i, _f, _f,
+                         _f, _i, _vp, _f, _vp],
+    "fcmf_bertadam": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
+                f"`make -C multimodal-aspect-category-sentiment-analysis_amd/csrc` (hipcc, gfx950). "
+                f"fcmf_framework has no CPU/PyTorch fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_char_p if name == "fcmf_build_info" else ctypes.c_int
+        _lib = l
+    return _lib
+
+
+_ERR = {-1: "bad argument", -2: "kernel launch failed", -3: "unsupported configuration"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float64:
+        return F64
+    raise HipLibraryError(f"unsupported dtype {t.dtype}")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise HipLibraryError("fcmf_framework ops run on the MI355X only: got a CPU tensor "
+                                  "(move the model and batch to 'cuda'; there is no CPU fallback)")

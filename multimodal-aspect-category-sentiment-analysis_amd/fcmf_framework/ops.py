@@ -1,0 +1,585 @@
+"""Autograd operators of the FCMF hot path, each a thin torch.autograd.Function over the C ABI
+of libfcmf_hip.so.  PyTorch supplies device memory, the stream and the autograd tape; every
+FLOP and every byte of the step runs in the hand-written gfx950 kernels.
+
+Activations are float32 (parity mode) or bfloat16 (throughput mode); master parameters and
+their gradients are always float32.  bf16 copies of the weights ("shadows") are cached and
+refreshed when the parameter changes.
+"""
+import math
+
+import torch
+
+from . import _hip as H
+
+# --------------------------------------------------------------------------------------
+# global state: dropout seeds and bf16 weight shadows
+# --------------------------------------------------------------------------------------
+_compute_dtype = torch.float32
+
+
+def set_compute_dtype(dtype):
+    """Activation storage type of the hot path: torch.float32 (parity) or torch.bfloat16 (MFMA)."""
+    global _compute_dtype
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _compute_dtype = dtype
+
+
+def compute_dtype():
+    return _compute_dtype
+
+
+_seed_base = 0x5DEECE66D
+_seed_ctr = 0
+
+
+def manual_seed(seed):
+    """Seed the counter-based dropout generator (independent of torch's generator)."""
+    global _seed_base, _seed_ctr
+    _seed_base = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+    _seed_ctr = 0
+
+
+def next_seed():
+    global _seed_ctr
+    _seed_ctr += 1
+    x = (_seed_base + _seed_ctr * 0xD1342543DE82EF95) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 29
+    return (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+
+
+class _Shadows:
+    """bf16 copies of float32 master parameters, keyed by storage address."""
+
+    def __init__(self):
+        self.map = {}
+
+    def get(self, w):
+        key = (w.data_ptr(), tuple(w.shape))
+        ent = self.map.get(key)
+        if ent is not None and ent[1] == w._version and not ent[2]:
+            return ent[0]
+        sh = ent[0] if ent is not None else torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+        src = w.detach()
+        if not src.is_contiguous():
+            src = src.contiguous()
+        H.check(H.lib().fcmf_cast(H.ptr(src), H.ptr(sh), src.numel(), H.F32, H.BF16, H.stream()), "fcmf_cast")
+        self.map[key] = [sh, w._version, False]
+        return sh
+
+    def peek(self, w):
+        ent = self.map.get((w.data_ptr(), tuple(w.shape)))
+        return None if ent is None else ent[0]
+
+    def mark_fresh(self, w):
+        ent = self.map.get((w.data_ptr(), tuple(w.shape)))
+        if ent is not None:
+            ent[1] = w._version
+            ent[2] = False
+
+    def mark_all_stale(self):
+        for ent in self.map.values():
+            ent[2] = True
+
+    def clear(self):
+        self.map.clear()
+
+
+shadows = _Shadows()
+
+
+def as_compute(w, dtype):
+    """parameter as seen by a kernel computing in `dtype`"""
+    if dtype == torch.float32:
+        return w.detach()
+    return shadows.get(w)
+
+
+def cast(x, dtype):
+    """dtype conversion through fcmf_cast (float32 <-> bfloat16)"""
+    if x.dtype == dtype:
+        return x
+    H.require_cuda(x)
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    H.check(H.lib().fcmf_cast(H.ptr(x), H.ptr(y), x.numel(), H.dt(x), H.dt(y), H.stream()), "fcmf_cast")
+    return y
+
+
+class _CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return cast(dy.contiguous(), ctx.src), None
+
+
+def cast_ad(x, dtype):
+    return x if x.dtype == dtype else _CastFn.apply(x, dtype)
+
+
+# --------------------------------------------------------------------------------------
+# raw kernel wrappers
+# --------------------------------------------------------------------------------------
+def _rows(x):
+    """2-D view [rows, features] with unit inner stride (row stride may be arbitrary)"""
+    if x.dim() != 2:
+        x = x.reshape(-1, x.shape[-1])
+    if x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) < x.shape[1]):
+        x = x.contiguous()
+    return x
+
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI_NONE, acc=False):
+    H.require_cuda(A, B, C)
+    H.check(H.lib().fcmf_gemm(H.ptr(A), H.ptr(B), H.ptr(C), H.ptr(bias), H.ptr(aux), M, N, K, lda, ldb, ldc,
+                              int(ta), int(tb), H.dt(A), H.dt(C), epi, int(acc), H.stream()), "fcmf_gemm")
+
+
+def colsum(X, M, N, ldx):
+    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    H.check(H.lib().fcmf_colsum(H.ptr(X), H.ptr(out), M, N, ldx, H.dt(X), 0, H.stream()), "fcmf_colsum")
+    return out
+
+
+def _ld(x):
+    return x.stride(0) if x.shape[0] > 1 else x.shape[1]
+
+
+def _linear_fwd(x, w, bias, epi=H.EPI_NONE, aux=None):
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    gemm(x, w, y, M, N, K, _ld(x), K, N, 0, 0, bias=bias, aux=aux, epi=epi)
+    return y
+
+
+def _linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=True, dx_epi=H.EPI_NONE, dx_aux=None):
+    """x [M,K], w [N,K] (compute dtype), dy [M,N] -> dx [M,K], dW [N,K] f32, db [N] f32"""
+    M, K = x.shape
+    N = w.shape[0]
+    dx = dw = db = None
+    if need_dx:
+        dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+        gemm(dy, w, dx, M, K, N, N, K, K, 0, 1, aux=dx_aux, epi=dx_epi)
+    if need_dw:
+        dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+        gemm(dy, x, dw, N, K, M, N, _ld(x), K, 1, 1, acc=True)
+    if need_db:
+        db = colsum(dy, M, N, N)
+    return dx, dw, db
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b), act in {none, tanh}.  nn.Linear (+ BertPooler's tanh, mm_modeling.py:425-431)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x2 = _rows(x)
+        w = as_compute(weight, x2.dtype)
+        epi = H.EPI_TANH if act == "tanh" else H.EPI_NONE
+        y = _linear_fwd(x2, w, None if bias is None else bias.detach(), epi)
+        ctx.save_for_backward(x2, weight, y if act == "tanh" else None)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, y = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        if ctx.act == "tanh":
+            d = torch.empty_like(dy2)
+            H.check(H.lib().fcmf_act_bwd(H.ptr(dy2), H.ptr(y), H.ptr(d), dy2.numel(), 0, H.dt(dy2), H.stream()), "act_bwd")
+            dy2 = d
+        w = as_compute(weight, x2.dtype)
+        dx, dw, db = _linear_bwd(x2, w, dy2, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                 ctx.has_bias and ctx.needs_input_grad[2])
+        return (None if dx is None else dx.view(ctx.xshape)), dw, db, None
+
+
+def linear(x, weight, bias=None, act=None):
+    return LinearFn.apply(x, weight, bias, act)
+
+
+class FFNFn(torch.autograd.Function):
+    """y = gelu_erf(x W1^T + b1) W2^T + b2   (BertIntermediate + BertOutput.dense,
+    mm_modeling.py:305-314,320; decoder PositionWiseFFN :558-565).  GELU is the epilogue of the
+    first GEMM; in the backward gelu' is the epilogue of the dA GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x2 = _rows(x)
+        c1, c2 = as_compute(w1, x2.dtype), as_compute(w2, x2.dtype)
+        M = x2.shape[0]
+        u = torch.empty((M, w1.shape[0]), dtype=x2.dtype, device=x2.device)
+        a = _linear_fwd(x2, c1, b1.detach(), H.EPI_GELU, aux=u)
+        y = _linear_fwd(a, c2, b2.detach())
+        ctx.save_for_backward(x2, w1, w2, u, a)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, u, a = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        c1, c2 = as_compute(w1, x2.dtype), as_compute(w2, x2.dtype)
+        du, dw2, db2 = _linear_bwd(a, c2, dy2, True, True, True, dx_epi=H.EPI_DGELU, dx_aux=u)
+        dx, dw1, db1 = _linear_bwd(x2, c1, du, ctx.needs_input_grad[0], True, True)
+        return (None if dx is None else dx.view(ctx.xshape)), dw1, db1, dw2, db2
+
+
+def ffn(x, w1, b1, w2, b2):
+    return FFNFn.apply(x, w1, b1, w2, b2)
+
+
+# --------------------------------------------------------------------------------------
+# residual + dropout + LayerNorm
+# --------------------------------------------------------------------------------------
+class AddLNFn(torch.autograd.Function):
+    """LN(dropout(x) + res): BertSelfOutput / BertOutput / AddNorm (mm_modeling.py:276-280,
+    324-328, 570-573) with FCMFLayerNorm (:167-171) or nn.LayerNorm (HF, eps 1e-5)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p, seed):
+        x2 = _rows(x).contiguous()
+        rows, Hd = x2.shape
+        r2 = None if res is None else _rows(res)
+        y = torch.empty_like(x2)
+        z = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+        H.require_cuda(x2)
+        H.check(H.lib().fcmf_add_ln_fwd(H.ptr(x2), H.ptr(r2), 0 if r2 is None else _ld(r2), H.ptr(gamma), H.ptr(beta),
+                                        H.ptr(y), H.ptr(z), H.ptr(mean), H.ptr(rstd), rows, Hd, eps, p, seed,
+                                        H.dt(x2), H.stream()), "fcmf_add_ln_fwd")
+        ctx.save_for_backward(z, gamma, mean, rstd)
+        ctx.p, ctx.seed, ctx.xshape = p, seed, x.shape
+        ctx.res_shape = None if res is None else res.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, gamma, mean, rstd = ctx.saved_tensors
+        rows, Hd = z.shape
+        dy2 = dy.reshape(rows, Hd).contiguous()
+        dz = torch.empty_like(z)
+        dx = torch.empty_like(z) if ctx.p > 0 else None
+        dg = torch.zeros(Hd, dtype=torch.float32, device=z.device)
+        db = torch.zeros(Hd, dtype=torch.float32, device=z.device)
+        H.check(H.lib().fcmf_add_ln_bwd(H.ptr(dy2), H.ptr(z), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(dz),
+                                        H.ptr(dx), H.ptr(dg), H.ptr(db), rows, Hd, ctx.p, ctx.seed, H.dt(z),
+                                        H.stream()), "fcmf_add_ln_bwd")
+        dxo = (dx if dx is not None else dz).view(ctx.xshape)
+        dres = None if ctx.res_shape is None else dz.view(ctx.res_shape)
+        return dxo, dres, dg, db, None, None, None
+
+
+def add_layer_norm(x, res, gamma, beta, eps, p=0.0, training=False):
+    p = float(p) if training else 0.0
+    return AddLNFn.apply(x, res, gamma, beta, float(eps), p, next_seed() if p > 0 else 0)
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x2 = x.contiguous()
+        y = torch.empty_like(x2)
+        H.require_cuda(x2)
+        H.check(H.lib().fcmf_dropout(H.ptr(x2), H.ptr(y), x2.numel(), p, seed, H.dt(x2), H.stream()), "fcmf_dropout")
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = dy.contiguous()
+        o = torch.empty_like(d)
+        H.check(H.lib().fcmf_dropout(H.ptr(d), H.ptr(o), d.numel(), ctx.p, ctx.seed, H.dt(d), H.stream()), "fcmf_dropout")
+        return o, None, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0:
+        return x
+    return DropoutFn.apply(x, float(p), next_seed())
+
+
+# --------------------------------------------------------------------------------------
+# RoBERTa embeddings
+# --------------------------------------------------------------------------------------
+def position_ids(input_ids, pad_id):
+    """HF create_position_ids_from_input_ids"""
+    ids = input_ids.contiguous()
+    H.require_cuda(ids)
+    pos = torch.empty_like(ids)
+    H.check(H.lib().fcmf_position_ids(H.ptr(ids), H.ptr(pos), ids.shape[0], ids.shape[1], pad_id, H.stream()),
+            "fcmf_position_ids")
+    return pos
+
+
+class EmbedLNFn(torch.autograd.Function):
+    """RobertaEmbeddings: LN(word[ids] + type[tt] + pos[pos]) then dropout"""
+
+    @staticmethod
+    def forward(ctx, ids, pos, tt, word, ptab, ttab, gamma, beta, eps, p, seed, pad_id, out_dtype):
+        ids, pos = ids.contiguous(), pos.contiguous()
+        tt = None if tt is None else tt.contiguous()
+        ntok, Hd = ids.numel(), word.shape[1]
+        y = torch.empty((ntok, Hd), dtype=out_dtype, device=word.device)
+        z = torch.empty_like(y)
+        mean = torch.empty(ntok, dtype=torch.float32, device=word.device)
+        rstd = torch.empty(ntok, dtype=torch.float32, device=word.device)
+        H.require_cuda(ids, word)
+        H.check(H.lib().fcmf_embed_ln_fwd(H.ptr(ids), H.ptr(pos), H.ptr(tt), H.ptr(word), H.ptr(ptab), H.ptr(ttab),
+                                          H.ptr(gamma), H.ptr(beta), H.ptr(y), H.ptr(z), H.ptr(mean), H.ptr(rstd),
+                                          ntok, Hd, eps, p, seed, H.dt(y), H.stream()), "fcmf_embed_ln_fwd")
+        ctx.save_for_backward(ids, pos, tt, z, gamma, mean, rstd)
+        ctx.p, ctx.seed, ctx.pad_id = p, seed, pad_id
+        ctx.shapes = (word.shape, ptab.shape, ttab.shape)
+        return y.view(*ids.shape, Hd)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, pos, tt, z, gamma, mean, rstd = ctx.saved_tensors
+        ntok, Hd = z.shape
+        d = dy.reshape(ntok, Hd).contiguous()
+        L = H.lib()
+        if ctx.p > 0:
+            o = torch.empty_like(d)
+            H.check(L.fcmf_dropout(H.ptr(d), H.ptr(o), d.numel(), ctx.p, ctx.seed, H.dt(d), H.stream()), "fcmf_dropout")
+            d = o
+        dz = torch.empty_like(z)
+        dg = torch.zeros(Hd, dtype=torch.float32, device=z.device)
+        db = torch.zeros(Hd, dtype=torch.float32, device=z.device)
+        H.check(L.fcmf_add_ln_bwd(H.ptr(d), H.ptr(z), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(dz), 0, H.ptr(dg),
+                                  H.ptr(db), ntok, Hd, 0.0, 0, H.dt(z), H.stream()), "fcmf_add_ln_bwd")
+        ws, ps, ts = ctx.shapes
+        dword = torch.zeros(ws, dtype=torch.float32, device=z.device)
+        dpos = torch.zeros(ps, dtype=torch.float32, device=z.device)
+        dtt = torch.zeros(ts, dtype=torch.float32, device=z.device)
+        H.check(L.fcmf_embed_bwd(H.ptr(dz), H.ptr(ids), H.ptr(pos), H.ptr(tt), H.ptr(dword), H.ptr(dpos), H.ptr(dtt),
+                                 ntok, Hd, ctx.pad_id, H.dt(dz), H.stream()), "fcmf_embed_bwd")
+        return None, None, None, dword, dpos, dtt, dg, db, None, None, None, None, None
+
+
+def embed_layer_norm(ids, pos, tt, word, ptab, ttab, gamma, beta, eps, p, training, pad_id, out_dtype):
+    p = float(p) if training else 0.0
+    return EmbedLNFn.apply(ids, pos, tt, word, ptab, ttab, gamma, beta, float(eps), p, next_seed() if p > 0 else 0,
+                           int(pad_id), out_dtype)
+
+
+# --------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------
+def _desc(q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal, head_quirk):
+    G, R, HD = q.shape
+    d = HD // heads
+    T1 = 0 if k1 is None else k1.shape[1]
+    T2 = 0 if k2 is None else k2.shape[2]
+    a = H.AttnDesc()
+    a.dtype, a.G, a.heads, a.d, a.R, a.T1, a.T2, a.group_div = H.dt(q), G, heads, d, R, T1, T2, group_div
+    a.q_sg, a.q_sr = q.stride(0), q.stride(1)
+    if k1 is not None:
+        a.k1_sg, a.k1_st = k1.stride(0), k1.stride(1)
+    if k2 is not None:
+        a.k2_sg, a.k2_sr, a.k2_st = k2.stride(0), k2.stride(1), k2.stride(2)
+    a.o_sg, a.o_sr = R * HD, HD
+    a.q, a.k1, a.v1, a.k2, a.v2 = H.ptr(q), H.ptr(k1), H.ptr(v1), H.ptr(k2), H.ptr(v2)
+    a.mask, a.bias = H.ptr(mask), H.ptr(bias)
+    a.scale, a.dropout_p, a.seed, a.causal, a.head_quirk = scale, p, seed, int(causal), int(head_quirk)
+    return a
+
+
+def _chk_same_layout(a, b):
+    if a is not None and (a.stride() != b.stride() or a.shape != b.shape):
+        raise H.HipLibraryError("attention: K and V of a segment must share shape and strides")
+
+
+class AttentionFn(torch.autograd.Function):
+    """Two-segment multi-head attention (see fcmf_attn_desc in include/fcmf_hip.h).
+      q  [G,R,heads*d]; k1/v1 [G,T1,heads*d] shared by the R rows of a group;
+      k2/v2 [G/group_div,R,T2,heads*d] private per row; mask [G,T1+T2] additive float32;
+      bias [G/group_div,heads,R,T1+T2] additive float32.  Returns [G,R,heads*d]."""
+
+    @staticmethod
+    def forward(ctx, q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal):
+        H.require_cuda(q)
+        q = q if q.stride(2) == 1 and q.stride(1) >= q.shape[2] else q.contiguous()
+        k1 = None if k1 is None else (k1 if k1.stride(2) == 1 else k1.contiguous())
+        v1 = None if v1 is None else (v1 if v1.stride() == k1.stride() else v1.contiguous())
+        if k1 is not None and v1.stride() != k1.stride():
+            k1 = k1.contiguous()
+        k2 = None if k2 is None else (k2 if k2.stride(3) == 1 else k2.contiguous())
+        v2 = None if v2 is None else (v2 if v2.stride() == k2.stride() else v2.contiguous())
+        if k2 is not None and v2.stride() != k2.stride():
+            k2 = k2.contiguous()
+        mask = None if mask is None else mask.contiguous().float()
+        bias = None if bias is None else bias.contiguous()
+        G, R, HD = q.shape
+        out = torch.empty((G, R, HD), dtype=q.dtype, device=q.device)
+        lse = torch.empty((G, heads, R), dtype=torch.float32, device=q.device)
+        a = _desc(q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal, 0)
+        H.check(H.lib().fcmf_attn_small_fwd(a, H.ptr(out), H.ptr(lse), H.stream()), "fcmf_attn_small_fwd")
+        ctx.save_for_backward(q, k1, v1, k2, v2, mask, bias, out, lse)
+        ctx.cfg = (heads, group_div, scale, p, seed, causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k1, v1, k2, v2, mask, bias, out, lse = ctx.saved_tensors
+        heads, group_div, scale, p, seed, causal = ctx.cfg
+        G, R, HD = q.shape
+        dout = dout.contiguous()
+        T1 = 0 if k1 is None else k1.shape[1]
+        nch = max(1, (T1 + 127) // 128)
+        dq = torch.empty((nch, G, R, HD), dtype=q.dtype, device=q.device)   # one partial per 128-key chunk
+        dk1 = dv1 = dk2 = dv2 = dbias = None
+        if k1 is not None:
+            dk1 = torch.empty((G, T1, HD), dtype=k1.dtype, device=q.device)
+            dv1 = torch.empty((G, T1, HD), dtype=k1.dtype, device=q.device)
+        T2 = 0 if k2 is None else k2.shape[2]
+        if k2 is not None:
+            dk2 = torch.empty((G, R, T2, HD), dtype=q.dtype, device=q.device)
+            dv2 = torch.empty((G, R, T2, HD), dtype=q.dtype, device=q.device)
+        if bias is not None and ctx.needs_input_grad[6]:
+            T = (0 if k1 is None else k1.shape[1]) + T2
+            dbias = torch.empty((G, heads, R, T), dtype=torch.float32, device=q.device)
+        a = _desc(q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal, 0)
+        H.check(H.lib().fcmf_attn_small_bwd(a, H.ptr(out), H.ptr(dout), H.ptr(lse), H.ptr(dq), H.ptr(dk1), H.ptr(dv1),
+                                            H.ptr(dk2), H.ptr(dv2), H.ptr(dbias), H.stream()), "fcmf_attn_small_bwd")
+        dq = _sum_leading(dq)
+        if group_div > 1:
+            if dk2 is not None:
+                dk2, dv2 = _sum_groups(dk2, group_div), _sum_groups(dv2, group_div)
+            if dbias is not None:
+                dbias = _sum_groups(dbias, group_div)
+        return dq, dk1, dv1, dk2, dv2, None, dbias, None, None, None, None, None, None
+
+
+def _sum_leading(x):
+    """[n, ...] -> [...] summing the leading axis (attention dq chunk partials)"""
+    if x.shape[0] == 1:
+        return x[0]
+    inner = x[0].numel()
+    out = torch.empty(x.shape[1:], dtype=x.dtype, device=x.device)
+    H.check(H.lib().fcmf_sum_axis(H.ptr(x), H.ptr(out), 1, x.shape[0], inner, H.dt(x), H.stream()), "fcmf_sum_axis")
+    return out
+
+
+def _sum_groups(x, reps):
+    """[G, ...] -> [G/reps, ...] summing consecutive groups"""
+    G = x.shape[0]
+    inner = x[0].numel()
+    out = torch.empty((G // reps,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    H.check(H.lib().fcmf_sum_axis(H.ptr(x), H.ptr(out), G // reps, reps, inner, H.dt(x), H.stream()), "fcmf_sum_axis")
+    return out
+
+
+def attention(q, k1=None, v1=None, k2=None, v2=None, mask=None, bias=None, heads=12, group_div=1, scale=None,
+              p=0.0, training=False, causal=False):
+    d = q.shape[-1] // heads
+    scale = 1.0 / math.sqrt(d) if scale is None else scale
+    p = float(p) if training else 0.0
+    return AttentionFn.apply(q, k1, v1, k2, v2, mask, bias, heads, group_div, float(scale), p,
+                             next_seed() if p > 0 else 0, causal)
+
+
+# --------------------------------------------------------------------------------------
+# box geometry
+# --------------------------------------------------------------------------------------
+_dim_mat_cache = {}
+
+
+def box_dim_mat(device):
+    """1/1000^(k/8), k=0..7, rounded exactly as roi_modeling.py:123-125 does (float32)"""
+    key = str(device)
+    if key not in _dim_mat_cache:
+        feat_range = torch.arange(64 / 8)
+        dm = 1.0 / torch.pow(1000, feat_range / (64 / 8))
+        _dim_mat_cache[key] = dm.float().to(device)
+    return _dim_mat_cache[key]
+
+
+class BoxBiasFn(torch.autograd.Function):
+    """log(clamp(relu(WG(emb(boxes))), 1e-6)) -> [G,heads,N,N] float32 (roi_modeling.py:148-163,40)"""
+
+    @staticmethod
+    def forward(ctx, coords, wg_w, wg_b):
+        c = coords.contiguous()
+        H.require_cuda(c, wg_w)
+        G, N, _ = c.shape
+        heads = wg_w.shape[0]
+        ww, wb = wg_w.detach().contiguous().float(), wg_b.detach().contiguous().float()
+        bias = torch.empty((G, heads, N, N), dtype=torch.float32, device=c.device)
+        H.check(H.lib().fcmf_box_bias_fwd(H.ptr(c), H.dt(c), H.ptr(box_dim_mat(c.device)), H.ptr(ww), H.ptr(wb),
+                                          H.ptr(bias), G, N, heads, H.stream()), "fcmf_box_bias_fwd")
+        ctx.save_for_backward(c, ww, wb)
+        return bias
+
+    @staticmethod
+    def backward(ctx, dbias):
+        c, ww, wb = ctx.saved_tensors
+        G, N, _ = c.shape
+        heads = ww.shape[0]
+        dw = torch.zeros_like(ww)
+        db = torch.zeros_like(wb)
+        d = dbias.contiguous().float()
+        H.check(H.lib().fcmf_box_bias_bwd(H.ptr(c), H.dt(c), H.ptr(box_dim_mat(c.device)), H.ptr(ww), H.ptr(wb), H.ptr(d),
+                                          H.ptr(dw), H.ptr(db), G, N, heads, H.stream()), "fcmf_box_bias_bwd")
+        return None, dw, db
+
+
+def box_bias(coords, wg_w, wg_b):
+    return BoxBiasFn.apply(coords, wg_w, wg_b)
+
+
+def box_embedding(coords):
+    c = coords.contiguous()
+    H.require_cuda(c)
+    G, N, _ = c.shape
+    emb = torch.empty((G, N, N, 64), dtype=torch.float32, device=c.device)
+    H.check(H.lib().fcmf_box_embedding(H.ptr(c), H.dt(c), H.ptr(box_dim_mat(c.device)), H.ptr(emb), G, N, H.stream()),
+            "fcmf_box_embedding")
+    return emb
+
+
+# --------------------------------------------------------------------------------------
+# cross entropy
+# --------------------------------------------------------------------------------------
+class XentFn(torch.autograd.Function):
+    """mean cross entropy over the non-ignored rows (torch.nn.CrossEntropyLoss semantics)"""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        lg = logits if logits.stride(-1) == 1 else logits.contiguous()
+        lg = lg.reshape(-1, lg.shape[-1]) if lg.dim() != 2 else lg
+        lb = labels.reshape(-1).contiguous()
+        H.require_cuda(lg, lb)
+        n, C = lg.shape
+        rows = torch.empty(n, dtype=torch.float32, device=lg.device)
+        nvalid = torch.zeros(1, dtype=torch.float32, device=lg.device)
+        H.check(H.lib().fcmf_xent_fwd(H.ptr(lg), lg.stride(0), H.ptr(lb), H.ptr(rows), H.ptr(nvalid), n, C, ignore_index,
+                                      H.dt(lg), H.stream()), "fcmf_xent_fwd")
+        ctx.save_for_backward(lg, lb, nvalid)
+        ctx.ignore_index = ignore_index
+        ctx.lshape = logits.shape
+        return rows.sum() / nvalid[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, lb, nvalid = ctx.saved_tensors
+        n, C = lg.shape
+        d = torch.empty((n, C), dtype=lg.dtype, device=lg.device)
+        scale = (g.float() / nvalid[0]).reshape(1).contiguous()
+        H.check(H.lib().fcmf_xent_bwd(H.ptr(lg), lg.stride(0), H.ptr(lb), H.ptr(d), C, H.ptr(scale), 1.0, n, C,
+                                      ctx.ignore_index, H.dt(lg), H.stream()), "fcmf_xent_bwd")
+        return d.view(ctx.lshape), None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    return XentFn.apply(logits, labels, int(ignore_index))

@@ -1,4 +1,4 @@
-"""Deterministic synthetic weights and batches -- TEST / BENCH INFRASTRUCTURE ONLY.
+"""Deterministic synthetic weights and batches (data generator only: no model arithmetic).
 
 No dataset, tokenizer or checkpoint is reachable offline, so both the
 golden fixtures and the benchmark use seeded synthetic data of the reference's shapes.

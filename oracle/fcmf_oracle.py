@@ -11,7 +11,7 @@ anything from `oracle/` and fails loudly if the HIP library is missing.
 
 Parity status: PINNED.  `oracle/make_golden.py` imports the reference package from
 /root/reference in the build container, runs it on seeded inputs/weights produced by
-`oracle/synth.py`, checks this restatement against it (<=1e-5) and commits the
+`synthetic_data.py`, checks this restatement against it (<=1e-5) and commits the
 reference's outputs as fixtures under tests/golden/.  `tests/test_oracle_golden.py`
 re-checks this file against those fixtures on every run.
 

@@ -3,7 +3,7 @@
 Run in the build container only (the reference never travels to the GPU box):
     python oracle/make_golden.py
 It (1) builds the reference FCMF / FCMFSeq2Seq / BertAdam with the deterministic synthetic
-weights of oracle/synth.py, (2) runs them on synthetic batches with dropout disabled
+weights of synthetic_data.py, (2) runs them on synthetic batches with dropout disabled
 (eval mode), (3) checks oracle/fcmf_oracle.py against the reference outputs (<=1e-5, the
 "pin"), and (4) stores the REFERENCE's outputs as small fixtures.  Fixtures hold data only
 (inputs are regenerated from seeds; outputs are arrays) -- no reference source text.
@@ -19,11 +19,12 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "multimodal-aspect-category-sentiment-analysis_amd"))
 sys.path.insert(0, "/root/reference")
 warnings.filterwarnings("ignore")
 
 from oracle import fcmf_oracle as O  # noqa: E402
-from oracle import synth  # noqa: E402
+import synthetic_data as synth  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)

@@ -1,0 +1,53 @@
+"""CPU-side checks of the C-ABI boundary: the library loads here (no GPU needed), exports every
+symbol include/fcmf_hip.h declares, and the ctypes binding covers exactly that set."""
+import ctypes
+import os
+import re
+
+from conftest import PKG, ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "fcmf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fcmf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    from fcmf_framework import _hip
+    names = _declared()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(os.path.join(PKG, "fcmf_framework", "libfcmf_hip.so"))
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fcmf_hip.h but not exported"
+    assert sorted(_hip.SIGNATURES) == names
+    l = _hip.lib()
+    assert l.fcmf_abi_version() == 1
+    assert b"gfx950" in l.fcmf_build_info()
+
+
+def test_attn_desc_layout_matches_header():
+    """field order of the ctypes mirror follows the C struct"""
+    from fcmf_framework import _hip
+    src = open(os.path.join(ROOT, "include", "fcmf_hip.h")).read()
+    body = src[src.index("typedef struct {"):src.index("} fcmf_attn_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(int64_t|uint64_t|int|float|void|const float)\s*\*?", "", decl).strip()
+        fields += [f.strip().lstrip("*") for f in decl.split(",")]
+    assert fields == [f[0] for f in _hip.AttnDesc._fields_]
+
+
+def test_missing_library_is_loud(tmp_path, monkeypatch):
+    from fcmf_framework import _hip
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _hip.lib()
+        raise AssertionError("expected HipLibraryError")
+    except _hip.HipLibraryError as e:
+        assert "no CPU/PyTorch fallback" in str(e)

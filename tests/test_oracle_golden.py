@@ -1,0 +1,105 @@
+"""The CPU oracle against the committed golden fixtures (outputs of the REFERENCE import,
+oracle/make_golden.py).  This is the pin that lets the oracle stand in for the reference on the GPU
+box, where /root/reference does not exist."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLD
+from oracle import fcmf_oracle as O
+import synthetic_data as synth
+
+
+def _fixture(tag, cfg):
+    z = np.load(os.path.join(GOLD, f"fcmf_{tag}.npz"))
+    B, S, NI, NR = int(z["B"]), int(z["S"]), int(z["NI"]), int(z["NR"])
+    P = synth.synth_params(synth.fcmf_param_shapes(cfg))
+    batch = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, seed=42)
+    return z, P, batch, NI, NR
+
+
+def test_oracle_tiny_forward_backward_step():
+    cfg = synth.TINY_CFG
+    z, P, batch, NI, NR = _fixture("tiny", cfg)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss, logits = O.fcmf_step_loss(Pg, cfg, batch, NI, NR)
+    assert (logits.detach() - torch.from_numpy(z["logits"])).abs().max() < 1e-5
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    loss.backward()
+    grads = {k: v.grad for k, v in Pg.items() if v.grad is not None}
+    for n, ref in zip(z["grad_names"], z["grad_norms"]):
+        n = str(n)
+        if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias"):
+            continue
+        assert abs(grads[n].norm().item() - ref) < 1e-4 * max(ref, 1e-3), n
+    assert all(Pg[str(n)].grad is None for n in z["nograd_names"])
+    # clip + AdamW (4 groups) + schedule factor 1/10, as the reference loop
+    clipped, total = O.clip_grad_norm(grads, 1.0)
+    assert abs(total.item() - float(z["total_grad_norm"])) < 1e-4 * float(z["total_grad_norm"])
+    f = O.linear_schedule_factor(1, 10, 100)
+    groups = O.fcmf_param_groups(list(grads))
+    for g in groups:
+        for n in g["names"]:
+            p1, _, _ = O.adamw_update(P[n], clipped[n], torch.zeros_like(P[n]), torch.zeros_like(P[n]), 1,
+                                      g["lr"] * f, g["weight_decay"])
+            key = "d_" + n
+            if key in z.files and not n.endswith(".key.bias"):
+                d = (p1 - P[n]).flatten()
+                if ("gidx_" + n) in z.files:
+                    d = d[torch.from_numpy(z["gidx_" + n])]
+                ref = torch.from_numpy(z[key])
+                gref = torch.from_numpy(z["g_" + n]).abs()
+                ok = gref > 1e-6 * gref.max()
+                assert (d[ok] - ref[ok]).abs().max() < 2e-3 * ref.abs().max(), n
+
+
+def test_oracle_base_logits():
+    """FCMF-base geometry, forward only (the backward pin ran inside oracle/make_golden.py)"""
+    cfg = synth.BASE_CFG
+    z, P, batch, NI, NR = _fixture("base", cfg)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        loss, logits = O.fcmf_step_loss(P, cfg, batch, NI, NR)
+    assert (logits - torch.from_numpy(z["logits"])).abs().max() < 1e-5
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+
+
+def test_oracle_box_embedding_known_answers():
+    z = np.load(os.path.join(GOLD, "box_embedding.npz"))
+    c = torch.from_numpy(z["coords"])
+    assert (O.box_relational_embedding(c) - torch.from_numpy(z["emb64"])).abs().max() < 1e-9
+    assert (O.box_relational_embedding(c.float()) - torch.from_numpy(z["emb32"])).abs().max() < 1e-5
+    assert torch.isfinite(torch.from_numpy(z["emb64"])).all()      # zero-padded boxes stay finite
+
+
+def test_oracle_bertadam_and_schedules():
+    z = np.load(os.path.join(GOLD, "bertadam.npz"))
+    p = torch.from_numpy(z["p0"])
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i, g in enumerate(z["grads"]):
+        p, m, v = O.bertadam_update(p, torch.from_numpy(g), m, v, i, 1e-2, 0.01, t_total=20, warmup=0.1)
+        assert (p - torch.from_numpy(z["traj"][i])).abs().max() < 1e-6
+    import fcmf_framework.optimization as opt
+    for x, wl, wc in zip(z["xs"], z["warmup_linear"], z["warmup_constant"]):
+        assert abs(opt.warmup_linear(float(x)) - wl) < 1e-12
+        assert abs(opt.warmup_constant(float(x)) - wc) < 1e-12
+
+
+def test_oracle_iaog_tiny():
+    z = np.load(os.path.join(GOLD, "iaog_tiny.npz"))
+    cfg = synth.TINY_CFG
+    V, NI, NR, B, S = cfg["vocab_size"], 2, 5, 3, 16
+    shapes = {k: v for k, v in synth.fcmf_param_shapes(cfg).items() if k.startswith("encoder.")}
+    shapes.update(synth.iaog_decoder_param_shapes(cfg, V))
+    P = dict(synth.synth_params(shapes))
+    P["decoder.dense.weight"] = P["encoder.bert.cell.embeddings.word_embeddings.weight"]
+    batch = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, seed=5, coord_dtype=torch.float32)
+    with torch.no_grad():
+        enc = O.fcmf_encoder_forward(P, cfg, batch["input_ids"][:, 0], batch["visual_embeds_att"],
+                                     batch["roi_embeds_att"], batch["roi_coors"], batch["token_type_ids"][:, 0],
+                                     batch["attention_mask"][:, 0], batch["added_attention_mask"][:, 0], NI, NR)
+        logits = O.iaog_decoder_forward(P, cfg, torch.from_numpy(z["dec"]), enc)
+    assert (logits[:, :, ::8] - torch.from_numpy(z["logits"])).abs().max() < 1e-5
+    loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), torch.from_numpy(z["labels"]), ignore_index=-100)
+    assert abs(loss.item() - float(z["loss"])) < 1e-5

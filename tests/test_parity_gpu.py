@@ -1,0 +1,254 @@
+"""Model-level parity of the HIP path (called through the fcmf_framework surface, i.e. through the
+C ABI) against (1) the committed golden fixtures produced by the REFERENCE import
+(oracle/make_golden.py) and (2) the CPU oracle on the same seeded inputs.
+
+Tolerances
+  fp32 path : logits / loss within 1e-3 absolute -- the bound BASELINE.json's north_star states
+              ("match the CPU reference within 1e-3 fp32"); measured errors are ~1e-5.
+  bf16 path : logits within 6e-2 absolute (bf16 activations: 8 significant bits through 12+ layers;
+              SURVEY.md section 5.9 measured 4.3e-3 for bf16 autocast on the reference itself).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+from helpers import batch_to, build_fcmf, max_err, rel_err
+from oracle import fcmf_oracle as O
+import synthetic_data as synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _set(dtype):
+    from fcmf_framework import ops
+    ops.set_compute_dtype(dtype)
+    ops.shadows.clear()
+
+
+def _run_aspects(model, batch):
+    return model.forward_aspects(batch["input_ids"], batch["visual_embeds_att"], batch["roi_embeds_att"],
+                                 batch["roi_coors"], batch["token_type_ids"], batch["attention_mask"],
+                                 batch["added_attention_mask"])
+
+
+def _run_per_aspect(model, batch):
+    outs = []
+    for a in range(batch["input_ids"].shape[1]):
+        outs.append(model(input_ids=batch["input_ids"][:, a], token_type_ids=batch["token_type_ids"][:, a],
+                          attention_mask=batch["attention_mask"][:, a],
+                          added_attention_mask=batch["added_attention_mask"][:, a],
+                          visual_embeds_att=batch["visual_embeds_att"], roi_embeds_att=batch["roi_embeds_att"],
+                          roi_coors=batch["roi_coors"]))
+    return torch.stack(outs, 1)
+
+
+@pytest.fixture(scope="module")
+def tiny(dev):
+    z = np.load(os.path.join(GOLD, "fcmf_tiny.npz"))
+    B, S, NI, NR = int(z["B"]), int(z["S"]), int(z["NI"]), int(z["NR"])
+    model, P = build_fcmf(synth.TINY_CFG, NI, NR, dev)
+    model.eval()
+    batch = synth.synth_batch(B, synth.TINY_CFG, S=S, num_imgs=NI, num_roi=NR, seed=42)
+    return z, model, P, batch
+
+
+def test_tiny_fp32_logits_loss_match_reference(tiny, dev):
+    z, model, P, batch = tiny
+    _set(torch.float32)
+    b = batch_to(batch, dev)
+    la = _run_aspects(model, b)
+    lp = _run_per_aspect(model, b)
+    assert max_err(la, torch.from_numpy(z["logits"])) < 1e-4
+    assert max_err(lp, torch.from_numpy(z["logits"])) < 1e-4      # drop-in per-aspect FCMF.forward
+    loss = model.loss_aspects(la, b["labels"])
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+
+
+def test_tiny_fp32_grads_and_adamw_step_match_reference(tiny, dev):
+    from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup
+    z, model, P, batch = tiny
+    _set(torch.float32)
+    model.load_state_dict(P)
+    b = batch_to(batch, dev)
+    model.zero_grad(set_to_none=True)
+    loss = model.loss_aspects(_run_aspects(model, b), b["labels"])
+    loss.backward()
+    named = dict(model.named_parameters())
+    names = [str(n) for n in z["grad_names"]]
+    for n, ref_norm in zip(names, z["grad_norms"]):
+        g = named[n].grad
+        assert g is not None, n
+        if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias"):
+            assert g.norm().item() < 1e-5          # analytically zero (softmax shift invariance)
+            continue
+        assert abs(g.norm().item() - ref_norm) < 2e-4 * max(ref_norm, 1e-3), n
+    for n in z["nograd_names"]:
+        assert named[str(n)].grad is None            # bert pooler: dead in training
+    for key in z.files:
+        if key.startswith("g_"):
+            n = key[2:]
+            g = named[n].grad.flatten().cpu()
+            if ("gidx_" + n) in z.files:
+                g = g[torch.from_numpy(z["gidx_" + n])]
+            ref = torch.from_numpy(z[key])
+            assert (g - ref).abs().max().item() < 2e-4 * max(ref.abs().max().item(), 1e-4), n
+    # ---- clip(1.0) + AdamW(4 groups) + linear warmup: one step, as in the reference loop ------
+    before = {n: p.detach().clone() for n, p in named.items()}
+    groups = O.fcmf_param_groups([n for n, p in named.items()])
+    opt = FusedAdamW([dict(params=[named[n] for n in g["names"]], weight_decay=g["weight_decay"], lr=g["lr"])
+                      for g in groups], lr=7e-4)
+    sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=10, num_training_steps=100)
+    sched.step()
+    opt.step(max_grad_norm=1.0)
+    assert abs(opt.grad_norm().item() - float(z["total_grad_norm"])) < 1e-3 * float(z["total_grad_norm"])
+    for n, ref_d in zip(names, z["delta_norms"]):
+        d = (named[n].detach() - before[n]).norm().item()
+        if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias"):
+            continue   # g ~ 0: Adam's sign-like update of rounding noise is not comparable
+        assert abs(d - ref_d) < 2e-3 * max(ref_d, 1e-7) + 1e-9, (n, d, ref_d)
+    for key in z.files:
+        if key.startswith("d_"):
+            n = key[2:]
+            if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias"):
+                continue
+            d = (named[n].detach() - before[n]).flatten().cpu()
+            if ("gidx_" + n) in z.files:
+                d = d[torch.from_numpy(z["gidx_" + n])]
+            ref = torch.from_numpy(z[key])
+            # elements whose gradient is ~0 get a +-lr update decided by rounding noise: compare where |ref g| is sane
+            gref = torch.from_numpy(z["g_" + n]).abs()
+            ok = gref > 1e-6 * gref.max()
+            assert (d[ok] - ref[ok]).abs().max().item() < 5e-3 * ref.abs().max().item(), n
+    model.load_state_dict(P)
+
+
+def test_tiny_bf16_close_to_reference(tiny, dev):
+    z, model, P, batch = tiny
+    model.load_state_dict(P)
+    _set(torch.bfloat16)
+    try:
+        la = _run_aspects(model, batch_to(batch, dev))
+        assert max_err(la, torch.from_numpy(z["logits"])) < 6e-2
+    finally:
+        _set(torch.float32)
+
+
+def test_tiny_intermediates_match_reference(tiny, dev):
+    """text-encoder output and the geometry-aware ROI block against the reference's hooks"""
+    z, model, P, batch = tiny
+    _set(torch.float32)
+    b = batch_to(batch, dev)
+    enc = model.encoder
+    seq = enc.bert.cell.encode(b["input_ids"][:, 0], b["token_type_ids"][:, 0], b["attention_mask"][:, 0])
+    assert max_err(seq, torch.from_numpy(z["inter_sequence_output"])) < 1e-4
+    from fcmf_framework import ops
+    roi = ops.linear(b["roi_embeds_att"][:, 0], enc.roimap2text.weight, enc.roimap2text.bias)
+    rel = enc.box_head(roi, roi, roi, b["roi_coors"][:, 0])
+    assert max_err(rel, torch.from_numpy(z["inter_rel0"])) < 1e-4
+    # dense (unpruned) module API: BertCrossEncoder on all rows equals the reference's layer output
+    img = ops.linear(b["visual_embeds_att"][:, 0], enc.vismap2text.weight, enc.vismap2text.bias)
+    ext = (1.0 - b["added_attention_mask"][:, 0, :49][:, None, None, :].float()) * -10000.0
+    t2i = enc.text2img_attention(seq, img, ext)[-1]
+    assert max_err(t2i, torch.from_numpy(z["inter_t2i0"])) < 1e-4
+
+
+@pytest.fixture(scope="module")
+def base(dev):
+    z = np.load(os.path.join(GOLD, "fcmf_base.npz"))
+    B, S, NI, NR = int(z["B"]), int(z["S"]), int(z["NI"]), int(z["NR"])
+    model, P = build_fcmf(synth.BASE_CFG, NI, NR, dev)
+    model.eval()
+    batch = synth.synth_batch(B, synth.BASE_CFG, S=S, num_imgs=NI, num_roi=NR, seed=42)
+    return z, model, batch
+
+
+def test_base_fp32_matches_reference_within_north_star_tolerance(base, dev):
+    """FCMF-base (156.46 M params), seq128 x 36 ROI x 7 images: logits / loss within 1e-3"""
+    z, model, batch = base
+    _set(torch.float32)
+    b = batch_to(batch, dev)
+    model.zero_grad(set_to_none=True)
+    la = _run_aspects(model, b)
+    assert max_err(la, torch.from_numpy(z["logits"])) < 1e-3
+    loss = model.loss_aspects(la, b["labels"])
+    assert abs(loss.item() - float(z["loss"])) < 1e-3
+    loss.backward()
+    named = dict(model.named_parameters())
+    for n, ref_norm in zip(z["grad_names"], z["grad_norms"]):
+        n = str(n)
+        if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias"):
+            continue
+        assert abs(named[n].grad.norm().item() - ref_norm) < 1e-3 * max(ref_norm, 1e-4), n
+    for key in z.files:
+        if key.startswith("g_"):
+            n = key[2:]
+            g = named[n].grad.flatten().cpu()
+            if ("gidx_" + n) in z.files:
+                g = g[torch.from_numpy(z["gidx_" + n])]
+            ref = torch.from_numpy(z[key])
+            assert (g - ref).abs().max().item() < 1e-3 * max(ref.abs().max().item(), 1e-6), n
+    model.zero_grad(set_to_none=True)
+
+
+def test_base_bf16_close_and_aspect_batching_is_exact(base, dev):
+    z, model, batch = base
+    b = batch_to(batch, dev)
+    _set(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            la = _run_aspects(model, b)
+            lp = _run_per_aspect(model, b)
+        assert max_err(la, torch.from_numpy(z["logits"])) < 6e-2
+        # batching the aspects must not change any row's arithmetic
+        assert max_err(la, lp) < 1e-6
+    finally:
+        _set(torch.float32)
+
+
+def test_full_size_properties_bf16(dev):
+    """BASELINE configs[1] geometry (seq128, 7 images, 36 ROIs, 6 aspects) at B=16: size-independent
+    properties -- determinism, batch-permutation equivariance, aspect batching == per-aspect calls."""
+    model, _ = build_fcmf(synth.BASE_CFG, 7, 36, dev)
+    model.eval()
+    _set(torch.bfloat16)
+    try:
+        b = batch_to(synth.synth_batch(16, synth.BASE_CFG, S=128, num_imgs=7, num_roi=36, seed=7), dev)
+        with torch.no_grad():
+            l1 = _run_aspects(model, b)
+            l2 = _run_aspects(model, b)
+            assert torch.equal(l1, l2)
+            perm = torch.randperm(16, generator=torch.Generator().manual_seed(0)).to(dev)
+            lp = _run_aspects(model, {k: v[perm] for k, v in b.items()})
+            assert max_err(lp, l1[perm]) < 1e-6
+            assert torch.isfinite(l1).all()
+    finally:
+        _set(torch.float32)
+
+
+def test_iaog_tiny_matches_reference(dev):
+    from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq
+    from fcmf_framework import ops
+    from helpers import make_hf_dir
+    z = np.load(os.path.join(GOLD, "iaog_tiny.npz"))
+    cfg = synth.TINY_CFG
+    V, NI, NR, B, S = cfg["vocab_size"], 2, 5, 3, 16
+    model = FCMFSeq2Seq(V, 20, make_hf_dir(cfg), NI, NR, 1.0)
+    model.decoder.embedding = torch.nn.Embedding(V, model.decoder.num_hiddens)   # run_pretraining_fcmf.py:189
+    shapes = {k: v for k, v in synth.fcmf_param_shapes(cfg).items() if k.startswith("encoder.")}
+    shapes.update(synth.iaog_decoder_param_shapes(cfg, V))
+    model.load_state_dict(synth.synth_params(shapes), strict=False)
+    model = model.to(dev).eval()
+    _set(torch.float32)
+    batch = batch_to(synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, seed=5, coord_dtype=torch.float32), dev)
+    dec = torch.from_numpy(z["dec"]).to(dev)
+    logits = model(batch["input_ids"][:, 0], dec, batch["visual_embeds_att"], batch["roi_embeds_att"],
+                   batch["roi_coors"], batch["token_type_ids"][:, 0], batch["attention_mask"][:, 0],
+                   batch["added_attention_mask"][:, 0], None, is_train=True)
+    assert max_err(logits[:, :, ::8], torch.from_numpy(z["logits"])) < 1e-4
+    loss = ops.cross_entropy(logits, torch.from_numpy(z["labels"]).to(dev), ignore_index=-100)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    loss.backward()
+    assert model.decoder.blks.block0.attention2.w_kx.grad is not None
