@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""FCMF fine-tune throughput on MI355X: train samples/sec (fwd + bwd + clip + AdamW step).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] per GPU: FCMF-base (PhoBERT-base geometry: H768 L12 heads12
+I3072 vocab 64001) bf16, batch 64 reviews x 6 aspects, seq 128, 7 images x (49 patches + 36 ROIs),
+precomputed ResNet-152 features, dropout on (p=0.1), 4-group AdamW + clip 1.0 + linear schedule.
+1 sample = 1 review = 6 aspect forwards (what the reference's tqdm counts).  Weak scaling: every
+rank processes its own 64-review shard; one gradient all-reduce (RCCL) per step.
+Synthetic data, random-init weights (no dataset / checkpoint is reachable offline); inputs are
+resident in HBM before the timed region.
+
+One JSON line on stdout (rank 0).  `roofline` describes the dominant kernel (the bf16 MFMA GEMM):
+achieved = executed GEMM FLOPs / summed launch durations measured with HIP events on the launch
+stream during the last timed step.  `cpu_baseline` times the CPU oracle (a port, not the product)
+on config C0 (B=4) on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "multimodal-aspect-category-sentiment-analysis_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
+
+BASE_CFG = dict(vocab_size=64001, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                intermediate_size=3072, max_position_embeddings=258, type_vocab_size=1, pad_token_id=1,
+                layer_norm_eps=1e-5, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")
+HEAD = ("classifier", "text_pooler")
+
+
+def param_groups(model, lr_enc=7e-5, lr_head=7e-4):
+    """4 groups by substring match on the names (run_multimodal_fcmf.py:249-287)"""
+    g = [dict(params=[], weight_decay=0.01, lr=lr_enc), dict(params=[], weight_decay=0.0, lr=lr_enc),
+         dict(params=[], weight_decay=0.01, lr=lr_head), dict(params=[], weight_decay=0.0, lr=lr_head)]
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        g[(2 if any(h in n for h in HEAD) else 0) + (1 if any(x in n for x in NO_DECAY) else 0)]["params"].append(p)
+    return g
+
+
+def algorithmic_flops_per_sample(cfg, S, NI, P, N, A, pruned):
+    """SURVEY.md section 8(d) formula (forward, per aspect) -> fwd+bwd (x3) per sample (x A)."""
+    H, I, Lyr = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+
+    def L(Tq, Tk):
+        return 2 * Tq * H * H + 4 * Tk * H * H + 4 * Tq * Tk * H + 2 * Tq * H * H + 4 * Tq * H * I
+    dense = (Lyr * L(S, S) + NI * (2 * P * 2048 * H + L(S, P) + 2 * N * 2048 * H + 8 * N * H * H + 16 * N * N * 64
+                                   + 4 * N * N * H + L(S + N, S + N) + 4 * H * H) + L(1 + 2 * NI, 1 + 2 * NI)
+             + 2 * H * H + 8 * H)
+    return 3 * A * dense
+
+
+def cpu_baseline(threads_note):
+    """the CPU oracle (torch-CPU restatement, `port`) on config C0: B=4, fp32, dropout on, AdamW"""
+    import synthetic_data as synth
+    from oracle import fcmf_oracle as O
+    cfg, NI, NR, B = synth.BASE_CFG, 7, 36, 4
+    P = {k: v.requires_grad_(True) for k, v in synth.synth_params(synth.fcmf_param_shapes(cfg)).items()}
+    groups = O.fcmf_param_groups(list(P))
+    opt = torch.optim.AdamW([dict(params=[P[n] for n in g["names"]], weight_decay=g["weight_decay"], lr=g["lr"])
+                             for g in groups], lr=7e-4)
+
+    def step(bsz, seed):
+        batch = synth.synth_batch(bsz, cfg, S=128, num_imgs=NI, num_roi=NR, seed=seed)
+        opt.zero_grad(set_to_none=True)
+        loss, _ = O.fcmf_step_loss(P, cfg, batch, NI, NR, training=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in P.values() if p.grad is not None], 1.0)
+        opt.step()
+    step(1, 1)                       # untimed warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    step(B, 2)
+    dt = time.perf_counter() - t0
+    return dict(value=round(B / dt, 4), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 step of config C0 (B=4 reviews x 6 aspects, seq128, 7x(49+36), fp32, dropout on, "
+                       f"clip+AdamW) after a B=1 warm-up; {dt:.1f} s; host cpu_count={os.cpu_count()}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="reviews per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import synthetic_data as synth
+    from fcmf_framework import ops
+    from fcmf_framework.dp import GradReducer
+    from fcmf_framework.fcmf_multimodal import FCMF
+    from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup
+    from fcmf_framework.roberta import RobertaConfig, RobertaModel
+
+    S, NI, NR, A, B = 128, 7, 36, 6, args.batch
+    torch.manual_seed(42)
+    hf = tempfile.mkdtemp(prefix="hf_")
+    RobertaModel(RobertaConfig(**BASE_CFG)).save_pretrained(hf)
+    model = FCMF(hf, num_labels=4, num_imgs=NI, num_roi=NR).to(dev)
+    model.train(not args.no_dropout)
+    ops.manual_seed(42 + rank)
+    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    opt = FusedAdamW(param_groups(model), lr=7e-4)
+    total_steps = args.steps + args.warmup
+    sched = get_linear_schedule_with_warmup(opt, int(0.1 * 1000), 1000)
+    red = GradReducer([p for n, p in model.named_parameters() if "bert.cell.pooler" not in n]) if world > 1 else None
+    if red is not None:
+        red.broadcast_parameters(0)
+    batch = {k: v.to(dev) for k, v in synth.synth_batch(B, BASE_CFG, S=S, num_imgs=NI, num_roi=NR, num_aspects=A,
+                                                        seed=42 + rank).items()}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = model.forward_aspects(batch["input_ids"], batch["visual_embeds_att"], batch["roi_embeds_att"],
+                                       batch["roi_coors"], batch["token_type_ids"], batch["attention_mask"],
+                                       batch["added_attention_mask"])
+        loss = model.loss_aspects(logits, batch["labels"])
+        loss.backward()
+        if red is not None:
+            red.finish()
+        opt.step(max_grad_norm=1.0)
+        sched.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            ops.gemm_trace_begin()       # HIP events around every GEMM launch of the last timed step
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    trace = ops.gemm_trace_end()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel family ------------------------------------------
+    per = {}
+    for name, flops, ms in trace:
+        e = per.setdefault(name, [0, 0.0, 0.0])
+        e[0] += 1; e[1] += flops; e[2] += ms
+    mf = {k: v for k, v in per.items() if k.startswith("gemm_bf16_kernel")}
+    roof = None
+    if mf:
+        dom = max(mf, key=lambda k: mf[k][2])
+        n, fl, ms = mf[dom]
+        tot_fl, tot_ms = sum(v[1] for v in mf.values()), sum(v[2] for v in mf.values())
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches=n,
+                    avg_launch_ms=round(ms / n, 4), flops_per_launch=fl / n,
+                    all_bf16_gemms=dict(launches=sum(v[0] for v in mf.values()), achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                                        ms_per_step=round(tot_ms, 3)),
+                    per_kernel={k: dict(launches=v[0], tflops=round(v[1] / (v[2] * 1e-3) / 1e12, 1), ms=round(v[2], 3))
+                                for k, v in sorted(per.items(), key=lambda kv: -kv[1][2])})
+    ms_step = dt / args.steps * 1e3
+    out = {
+        "metric": "train samples/sec (fwd+bwd+step) FCMF seq128x36ROI",
+        "value": round(world * B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (seeded batch, random-init weights)",
+        "config": {"workload": "FCMF-base fine-tune step, BASELINE configs[1]: batch 64 reviews x 6 aspects per GPU, "
+                               "seq 128, 7 images x (49 patches + 36 ROIs), precomputed ResNet-152 features, dropout "
+                               + ("off" if args.no_dropout else "0.1") + ", clip 1.0 + 4-group AdamW + linear schedule",
+                   "global_batch": world * B, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
+                   "sample_unit": "1 review = 6 aspect forwards",
+                   "dense_flops_per_sample_fwd_bwd": algorithmic_flops_per_sample(BASE_CFG, S, NI, 49, NR, A, False)},
+        "loss": round(float(loss.item()), 4),
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline("")
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

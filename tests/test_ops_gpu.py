@@ -305,7 +305,8 @@ def test_box_bias(dev, cdtype):
     tol = 1e-4 if cdtype == torch.float64 else 5e-3
     live = ref > math.log(2e-6)            # away from the clamp boundary
     assert (bias.cpu()[live] - ref[live]).abs().max().item() < tol
-    assert rel_err(ww.grad, wr.grad) < 1e-3 and rel_err(wb.grad, br.grad) < 1e-3
+    gtol = 1e-3 if cdtype == torch.float64 else 1e-2   # 1/x near the clamp amplifies f32-coordinate rounding
+    assert rel_err(ww.grad, wr.grad) < gtol and rel_err(wb.grad, br.grad) < gtol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -104,9 +104,10 @@ def test_tiny_fp32_grads_and_adamw_step_match_reference(tiny, dev):
     sched.step()
     opt.step(max_grad_norm=1.0)
     assert abs(opt.grad_norm().item() - float(z["total_grad_norm"])) < 1e-3 * float(z["total_grad_norm"])
+    gn = dict(zip(names, z["grad_norms"]))
     for n, ref_d in zip(names, z["delta_norms"]):
         d = (named[n].detach() - before[n]).norm().item()
-        if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias"):
+        if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias") or gn[n] < 1e-6:
             continue   # g ~ 0: Adam's sign-like update of rounding noise is not comparable
         assert abs(d - ref_d) < 2e-3 * max(ref_d, 1e-7) + 1e-9, (n, d, ref_d)
     for key in z.files:
