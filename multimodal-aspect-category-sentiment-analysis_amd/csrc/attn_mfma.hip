@@ -1,7 +1,388 @@
-// placeholder until the MFMA attention lands (entry points return UNSUPPORTED)
+// MFMA attention for the text-encoder layers: bf16, head dim 64, Tk <= 128 keys per (sequence, head).
+//   forward : one workgroup per (sequence, head, 128-query tile); K and V tiles staged once in LDS;
+//             each of the 4 waves owns 32 query rows: S^T = K Q^T on v_mfma_f32_16x16x32_bf16 with the
+//             key index in the accumulator registers (row max / sum = 32 in-lane values + 2 shuffles),
+//             P round-trips through a per-wave LDS tile, O^T = V^T P^T with V consumed through
+//             ds_read_b64_tr_b16 straight from its row-major image.
+//   backward: one workgroup per (sequence, head), Tq <= 128: P is recomputed from the saved logsumexp;
+//             phase 1 (wave = 32 query rows) builds Pdrop^T and dS^T [key][query] in LDS, phase 2
+//             (wave = 32 keys / 32 queries) forms dV, dK, dQ as 96 MFMAs per wave, no atomics.
+// One LDS image per tile serves both row reads (ds_read_b128) and transposed reads
+// (ds_read_b64_tr_b16); swizzles verified conflict-free with tools/lds_conflicts.py.
 #include "common.h"
-extern "C" int fcmf_attn_mfma_fwd(const void*, const void*, const void*, const float*, void*, float*, int, int, int, int,
-                                  int64_t, int64_t, int64_t, float, float, uint64_t, void*) { return FCMF_ERR_UNSUPPORTED; }
-extern "C" int fcmf_attn_mfma_bwd(const void*, const void*, const void*, const float*, const void*, const void*, const float*,
-                                  void*, void*, void*, int, int, int, int, int64_t, int64_t, int64_t, float, float, uint64_t,
-                                  void*) { return FCMF_ERR_UNSUPPORTED; }
+
+constexpr int AD = 64;             // head dim
+constexpr int AT = 128;            // tile rows (queries / keys)
+constexpr int TILE_B = AT * AD * 2;  // 16 KiB
+
+// [rows][64 bf16] tile, 128-B rows: 32-B pair index XOR ((r>>1)&1 | ((r>>3)&1)<<1)
+__device__ __forceinline__ int vkey(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
+__device__ __forceinline__ int off64(int r, int c8) { return r * 128 + ((((c8 >> 1) ^ vkey(r))) << 5) + ((c8 & 1) << 4); }
+// [128][128 bf16] tile, 256-B rows, 16-B chunk XOR ((r&3)<<2 | (r>>2)&3)
+__device__ __forceinline__ int key16(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ int off128(int r, int ch) { return r * 256 + ((ch ^ key16(r)) << 4); }
+// per-wave P tile of the forward [32][128 bf16]: chunk XOR (row & 15)
+__device__ __forceinline__ int offp(int r, int ch) { return r * 256 + ((ch ^ (r & 15)) << 4); }
+
+typedef bf16x4 __attribute__((address_space(3))) * lds_v4_t;
+
+// stage a [rows<=128][64] bf16 tile (row stride ld elements) into the off64 image, zero-filling
+__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* __restrict__ src, int64_t ld, int rows, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, r = c >> 3, c8 = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < rows) v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + c8 * 8);
+    *reinterpret_cast<uint4*>(lds + off64(r, c8)) = v;
+  }
+}
+// MFMA operand (rows x0..x0+15, k-step s over the 64 columns) by row read
+__device__ __forceinline__ bf16x8 frag_row64(const char* lds, int x0, int s, int lane) {
+  return *reinterpret_cast<const bf16x8*>(lds + off64(x0 + (lane & 15), 4 * s + (lane >> 4)));
+}
+// MFMA operand whose "row" index is the tile COLUMN (c0..c0+15) and whose k index is the tile ROW
+// (32*s .. 32*s+31): transposed read of the row-major image
+__device__ __forceinline__ bf16x8 frag_tr64(const char* lds, int c0, int s, int lane) {
+  const int g4 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p = i16 & 3;
+  const int r = 32 * s + 8 * g4 + q4, c8 = (c0 >> 3) + (p >> 1);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(lds + off64(r, c8) + (p & 1) * 8));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(lds + off64(r + 4, c8) + (p & 1) * 8));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3]; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+__device__ __forceinline__ bf16x8 frag_row128(const char* lds, int x0, int s, int lane) {
+  return *reinterpret_cast<const bf16x8*>(lds + off128(x0 + (lane & 15), 4 * s + (lane >> 4)));
+}
+__device__ __forceinline__ bf16x8 frag_tr128(const char* lds, int c0, int s, int lane) {
+  const int g4 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p = i16 & 3;
+  const int r = 32 * s + 8 * g4 + q4, ch = (c0 >> 3) + (p >> 1);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(lds + off128(r, ch) + (p & 1) * 8));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(lds + off128(r + 4, ch) + (p & 1) * 8));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3]; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+  bf16x4 o;
+  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+struct AttnMfmaParams {
+  const bf16_t *q, *k, *v, *o, *dout;
+  const float* mask;
+  bf16_t *out, *dq, *dk, *dv;
+  float* lse;
+  int G, heads, Tq, Tk;
+  int64_t ldq, ldk, ldo;
+  float scale, p;
+  uint64_t seed;
+};
+
+// =========================================================================================
+__global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnMfmaParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  char* Pw = smem + 2 * TILE_B + w * (32 * 256);
+  const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
+  const int q0 = blockIdx.y * AT + w * 32;
+  stage_tile(Ks, P.k + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
+  stage_tile(Vs, P.v + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
+
+  // Q fragments straight from global memory in operand layout (16 B per lane)
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int row = q0 + 16 * f + (lane & 15);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < P.Tq) v = *reinterpret_cast<const uint4*>(P.q + ((int64_t)g * P.Tq + row) * P.ldq + h * AD + 32 * s + 8 * (lane >> 4));
+      qf[f][s] = *reinterpret_cast<bf16x8*>(&v);
+    }
+  __syncthreads();
+
+  // S^T[key][q]: 8 key fragments x 2 query fragments
+  f32x4 sc[8][2];
+#pragma unroll
+  for (int kf = 0; kf < 8; ++kf)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) sc[kf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int kf = 0; kf < 8; ++kf) {
+      const bf16x8 ka = frag_row64(Ks, 16 * kf, s, lane);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) sc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[f][s], sc[kf][f], 0, 0, 0);
+    }
+  // lane holds, for query q0+16f+(lane&15), keys 16kf + 4(lane>>4) + r
+  const float inv_keep = P.p > 0.f ? 1.0f / (1.0f - P.p) : 1.0f;
+  const float* mrow = P.mask ? P.mask + (int64_t)g * P.Tk : nullptr;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int q = q0 + 16 * f + (lane & 15);
+    float m = -INFINITY;
+#pragma unroll
+    for (int kf = 0; kf < 8; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kf + 4 * (lane >> 4) + r;
+        float s = -INFINITY;
+        if (key < P.Tk) s = sc[kf][f][r] * P.scale + (mrow ? mrow[key] : 0.f);
+        sc[kf][f][r] = s;
+        m = fmaxf(m, s);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kf = 0; kf < 8; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(sc[kf][f][r] - m);
+        sc[kf][f][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (q < P.Tq && (lane >> 4) == 0 && P.lse) P.lse[((int64_t)g * P.heads + h) * P.Tq + q] = m + __logf(sum);
+#pragma unroll
+    for (int kf = 0; kf < 8; ++kf) {
+      f32x4 pv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = sc[kf][f][r] * inv;
+        if (P.p > 0.f) {
+          const int key = 16 * kf + 4 * (lane >> 4) + r;
+          x *= dropout_mult(P.seed, (((uint64_t)g * P.heads + h) * P.Tq + q) * P.Tk + key, P.p, inv_keep);
+        }
+        pv[r] = x;
+      }
+      store4(reinterpret_cast<bf16_t*>(Pw + offp(16 * f + (lane & 15), 2 * kf + (lane >> 5)) + ((lane >> 4) & 1) * 8), pv);
+    }
+  }
+  __syncthreads();
+  // O^T[d][q] = sum_key V[key][d] P[q][key]
+  f32x4 oc[4][2];
+#pragma unroll
+  for (int df = 0; df < 4; ++df)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) oc[df][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    bf16x8 pb[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+      pb[f] = *reinterpret_cast<const bf16x8*>(Pw + offp(16 * f + (lane & 15), 4 * s + (lane >> 4)));
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      const bf16x8 va = frag_tr64(Vs, 16 * df, s, lane);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) oc[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[f], oc[df][f], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int q = q0 + 16 * f + (lane & 15);
+    if (q < P.Tq) {
+      bf16_t* orow = P.out + ((int64_t)g * P.Tq + q) * P.ldo + h * AD + 4 * (lane >> 4);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) store4(orow + 16 * df, oc[df][f]);
+    }
+  }
+}
+
+// =========================================================================================
+__global__ __launch_bounds__(256, 1) void attn_mfma_bwd_kernel(AttnMfmaParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* Ks = smem + TILE_B;
+  char* Vs = smem + 2 * TILE_B;
+  char* dOs = smem + 3 * TILE_B;
+  char* PdT = smem + 4 * TILE_B;              // [128 keys][128 q] bf16, 32 KiB
+  char* dST = PdT + 2 * TILE_B;               // 32 KiB
+  float* delta = reinterpret_cast<float*>(dST + 2 * TILE_B);  // [128]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
+  const int64_t qbase = (int64_t)g * P.Tq, kbase = (int64_t)g * P.Tk;
+  stage_tile(Qs, P.q + qbase * P.ldq + h * AD, P.ldq, P.Tq, tid);
+  stage_tile(Ks, P.k + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
+  stage_tile(Vs, P.v + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
+  stage_tile(dOs, P.dout + qbase * P.ldo + h * AD, P.ldo, P.Tq, tid);
+  {  // delta[q] = sum_d dO[q][d] O[q][d]: two threads per query row
+    const int q = tid >> 1, half = tid & 1;
+    float s = 0.f;
+    if (q < P.Tq) {
+      const bf16_t* a = P.dout + (qbase + q) * P.ldo + h * AD + 32 * half;
+      const bf16_t* b = P.o + (qbase + q) * P.ldo + h * AD + 32 * half;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + 8 * i);
+        const bf16x8 y = *reinterpret_cast<const bf16x8*>(b + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)x[j] * (float)y[j];
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    if (half == 0) delta[q] = s;
+  }
+  __syncthreads();
+
+  // ---- phase 1: wave w = query rows 32w..32w+31; S and dP with D[q][key] --------------------
+  const float inv_keep = P.p > 0.f ? 1.0f / (1.0f - P.p) : 1.0f;
+  const float* mrow = P.mask ? P.mask + kbase : nullptr;
+  bf16x8 qa[2][2], da[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      qa[f][s] = frag_row64(Qs, 32 * w + 16 * f, s, lane);
+      da[f][s] = frag_row64(dOs, 32 * w + 16 * f, s, lane);
+    }
+  float lse4[2][4], dl4[2][4];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = 32 * w + 16 * f + 4 * (lane >> 4) + r;
+      lse4[f][r] = q < P.Tq ? P.lse[((int64_t)g * P.heads + h) * P.Tq + q] : 0.f;
+      dl4[f][r] = delta[q];
+    }
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg) {
+    f32x4 sS[4][2], sP[4][2];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) { sS[k4][f] = f32x4{0.f, 0.f, 0.f, 0.f}; sP[k4][f] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const bf16x8 kb = frag_row64(Ks, 16 * (4 * kg + k4), s, lane);
+        const bf16x8 vb = frag_row64(Vs, 16 * (4 * kg + k4), s, lane);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          sS[k4][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[f][s], kb, sS[k4][f], 0, 0, 0);
+          sP[k4][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[f][s], vb, sP[k4][f], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int key = 16 * (4 * kg + k4) + (lane & 15);
+      const float mk = (mrow && key < P.Tk) ? mrow[key] : 0.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        f32x4 pdv, dsv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 32 * w + 16 * f + 4 * (lane >> 4) + r;
+          float pr = 0.f, mult = 1.0f;
+          if (key < P.Tk && q < P.Tq) pr = __expf(sS[k4][f][r] * P.scale + mk - lse4[f][r]);
+          if (P.p > 0.f) mult = dropout_mult(P.seed, (((uint64_t)g * P.heads + h) * P.Tq + q) * P.Tk + key, P.p, inv_keep);
+          pdv[r] = pr * mult;
+          dsv[r] = pr * (sP[k4][f][r] * mult - dl4[f][r]);
+        }
+        const int ch = 4 * w + 2 * f + (lane >> 5);
+        const int o = off128(key, ch) + ((lane >> 4) & 1) * 8;
+        store4(reinterpret_cast<bf16_t*>(PdT + o), pdv);
+        store4(reinterpret_cast<bf16_t*>(dST + o), dsv);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: wave w owns keys 32w.. (dV, dK) and queries 32w.. (dQ) ------------------------
+  f32x4 aV[4][2], aK[4][2], aQ[4][2];
+#pragma unroll
+  for (int df = 0; df < 4; ++df)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) { aV[df][f] = f32x4{0.f, 0.f, 0.f, 0.f}; aK[df][f] = f32x4{0.f, 0.f, 0.f, 0.f}; aQ[df][f] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    bf16x8 pb[2], sb[2], tb[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      pb[f] = frag_row128(PdT, 32 * w + 16 * f, s, lane);   // B[k=q][col=key]
+      sb[f] = frag_row128(dST, 32 * w + 16 * f, s, lane);
+      tb[f] = frag_tr128(dST, 32 * w + 16 * f, s, lane);    // B[k=key][col=q]
+    }
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      const bf16x8 oa = frag_tr64(dOs, 16 * df, s, lane);   // A[row=d][k=q]
+      const bf16x8 qa2 = frag_tr64(Qs, 16 * df, s, lane);
+      const bf16x8 ka2 = frag_tr64(Ks, 16 * df, s, lane);   // A[row=d][k=key]
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        aV[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, pb[f], aV[df][f], 0, 0, 0);
+        aK[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa2, sb[f], aK[df][f], 0, 0, 0);
+        aQ[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka2, tb[f], aQ[df][f], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int x = 32 * w + 16 * f + (lane & 15);   // key index for dK/dV, query index for dQ
+    const int dcol = h * AD + 4 * (lane >> 4);
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      if (x < P.Tk) {
+        store4(P.dv + (kbase + x) * P.ldk + dcol + 16 * df, aV[df][f]);
+        f32x4 t = aK[df][f];
+        t[0] *= P.scale; t[1] *= P.scale; t[2] *= P.scale; t[3] *= P.scale;
+        store4(P.dk + (kbase + x) * P.ldk + dcol + 16 * df, t);
+      }
+      if (x < P.Tq) {
+        f32x4 t = aQ[df][f];
+        t[0] *= P.scale; t[1] *= P.scale; t[2] *= P.scale; t[3] *= P.scale;
+        store4(P.dq + (qbase + x) * P.ldq + dcol + 16 * df, t);
+      }
+    }
+  }
+}
+
+// =========================================================================================
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int fcmf_attn_mfma_fwd(const void* q, const void* k, const void* v, const float* mask, void* out, float* lse,
+                                  int G, int heads, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
+                                  float dropout_p, uint64_t seed, void* stream) {
+  if (!q || !k || !v || !out || G <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0) return FCMF_ERR_ARG;
+  if (Tk > AT || ldq % 8 || ldk % 8 || ldo % 4 || !al16(q) || !al16(k) || !al16(v) || !al16(out)) return FCMF_ERR_UNSUPPORTED;
+  AttnMfmaParams P{};
+  P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.mask = mask; P.out = (bf16_t*)out; P.lse = lse;
+  P.G = G; P.heads = heads; P.Tq = Tq; P.Tk = Tk; P.ldq = ldq; P.ldk = ldk; P.ldo = ldo;
+  P.scale = scale; P.p = dropout_p; P.seed = seed;
+  const int smem = 2 * TILE_B + 4 * 32 * 256;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+  hipLaunchKernelGGL(attn_mfma_fwd_kernel, dim3(G * heads, (Tq + AT - 1) / AT), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_attn_mfma_bwd(const void* q, const void* k, const void* v, const float* mask, const void* out,
+                                  const void* dout, const float* lse, void* dq, void* dk, void* dv, int G, int heads,
+                                  int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldo, float scale, float dropout_p,
+                                  uint64_t seed, void* stream) {
+  if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || G <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0) return FCMF_ERR_ARG;
+  if (Tk > AT || Tq > AT || ldq % 8 || ldk % 8 || ldo % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(out) || !al16(dout) ||
+      !al16(dq) || !al16(dk) || !al16(dv))
+    return FCMF_ERR_UNSUPPORTED;
+  AttnMfmaParams P{};
+  P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.mask = mask; P.o = (const bf16_t*)out;
+  P.dout = (const bf16_t*)dout; P.lse = const_cast<float*>(lse); P.dq = (bf16_t*)dq; P.dk = (bf16_t*)dk; P.dv = (bf16_t*)dv;
+  P.G = G; P.heads = heads; P.Tq = Tq; P.Tk = Tk; P.ldq = ldq; P.ldk = ldk; P.ldo = ldo;
+  P.scale = scale; P.p = dropout_p; P.seed = seed;
+  const int smem = 8 * TILE_B + 128 * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+  hipLaunchKernelGGL(attn_mfma_bwd_kernel, dim3(G * heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}

@@ -12,7 +12,30 @@ struct GemmParams {
   int M, N, K;
   int64_t lda, ldb, ldc;
   int epilogue, accumulate, ksplit, ktiles_per_split;
+  unsigned a_bytes, b_bytes;   // extents of A / B for the buffer range check
 };
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp + one v_exp + 6 FMAs instead of
+// the branchy libm erff.  Used only where the result is rounded to bf16 (8 significant bits).
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float y = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float apply_epilogue_fast(float v, int epi, float auxv) {
+  switch (epi) {
+    case FCMF_EPI_GELU: return v * 0.5f * (1.0f + erf_fast(v * 0.70710678118654752440f));
+    case FCMF_EPI_TANH: return tanhf(v);
+    case FCMF_EPI_DGELU: {
+      const float cdf = 0.5f * (1.0f + erf_fast(auxv * 0.70710678118654752440f));
+      return v * (cdf + auxv * 0.39894228040143267794f * __expf(-0.5f * auxv * auxv));
+    }
+    case FCMF_EPI_DTANH: return v * (1.0f - auxv * auxv);
+    default: return v;
+  }
+}
 
 __device__ __forceinline__ float apply_epilogue(float v, int epi, float auxv) {
   switch (epi) {
@@ -25,68 +48,57 @@ __device__ __forceinline__ float apply_epilogue(float v, int epi, float auxv) {
 }
 
 // =========================================================================================
-// bf16 MFMA kernel
+// bf16 MFMA kernel: 128x128 block tile, BK = 32, 4 waves (2x2, 64x64 each), 4-stage LDS ring
+// filled by LDS-DMA (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write), three k-tiles
+// in flight behind a counted s_waitcnt vmcnt and ONE raw s_barrier per k-tile; 64 KiB of LDS so
+// that two workgroups share a CU (one's epilogue / prologue hides under the other's MFMAs).
 // =========================================================================================
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile (16 KiB) in either layout
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int NSTAGE = 4;
+constexpr int TILE_BYTES = 128 * BK * 2;   // one operand tile: 8 KiB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 
-// LDS image of a K-contiguous operand tile [128 rows][64 k]: 128-B rows, 16-B chunk index XORed
-// with (row & 7) -> ds_read_b128 fragment reads are conflict free (checked per 16-lane group).
-__device__ __forceinline__ int lds_off_rowmajor(int r, int kc) { return r * 128 + ((kc ^ (r & 7)) << 4); }
-// LDS image of a transposed operand tile [64 k][128 x] (x contiguous, 256-B rows): the 32-B
-// column pair index is XORed with key(k) = (k&3) | ((k>>3)&1)<<2 so that the 8 rows one
-// 32-lane half touches in a ds_read_b64_tr_b16 land in 8 distinct 32-B slots.
+typedef __attribute__((address_space(3))) void* lds_void_t;
+
+// Image of a K-contiguous operand tile [128 rows][32 k] (64-B rows): 16-B chunk index c (0..3)
+// stored at c ^ (bit3(row) << 1): the ds_read_b128 fragment reads are conflict free.
+__device__ __forceinline__ int swz_row(int r) { return ((r >> 3) & 1) << 1; }
+// Image of a transposed operand tile [32 k][128 x] (x contiguous, 256-B rows): 32-B pair index
+// XOR key(k) = (k&3) | ((k>>3)&1)<<2: the ds_read_b64_tr_b16 reads are conflict free.
 __device__ __forceinline__ int tr_key(int kk) { return (kk & 3) | (((kk >> 3) & 1) << 2); }
-__device__ __forceinline__ int lds_off_tr(int kk, int c16) {
-  return kk * 256 + ((((c16 >> 1) ^ tr_key(kk))) << 5) + ((c16 & 1) << 4);
-}
+// (both verified with tools/lds_conflicts.py)
 
+// LDS-DMA writes LDS linearly (wave-uniform base + lane*16), so the swizzle is applied to the
+// per-lane SOURCE address: lane -> linear 16-B slot -> (row, physical chunk) -> logical chunk.
+// Returns the byte offset of the lane's 16 B inside the operand for k-tile 0 (0x80000000 = out
+// of range: the buffer range check then returns zeros).
 template <bool TR>
-__device__ __forceinline__ void load_tile_global(const bf16_t* __restrict__ X, int64_t ld, int x0, int xdim,
-                                                 int k0, int K, int tid, uint4 (&regs)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (!TR) {
-      int r = (tid >> 3) + 32 * i, kc = tid & 7;
-      int gx = x0 + r, gk = k0 + kc * 8;
-      if (gx < xdim && gk < K) v = *reinterpret_cast<const uint4*>(X + (int64_t)gx * ld + gk);
-    } else {
-      int kk = (tid >> 4) + 16 * i, xc = tid & 15;
-      int gk = k0 + kk, gx = x0 + xc * 8;
-      if (gk < K && gx < xdim) v = *reinterpret_cast<const uint4*>(X + (int64_t)gk * ld + gx);
-    }
-    regs[i] = v;
-  }
-}
-
-template <bool TR>
-__device__ __forceinline__ void store_tile_lds(char* lds, int tid, const uint4 (&regs)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int off;
-    if (!TR) { int r = (tid >> 3) + 32 * i, kc = tid & 7; off = lds_off_rowmajor(r, kc); }
-    else { int kk = (tid >> 4) + 16 * i, xc = tid & 15; off = lds_off_tr(kk, xc); }
-    *reinterpret_cast<uint4*>(lds + off) = regs[i];
-  }
-}
-
-// fragment for the 16 rows/cols [x0, x0+16) and k-step s (32 k) of the tile: 8 bf16 per lane,
-// lane l holds x = x0 + (l&15), k = 32*s + 8*(l>>4) + j.
-template <bool TR>
-__device__ __forceinline__ bf16x8 read_frag(const char* lds, int x0, int s, int lane) {
+__device__ __forceinline__ unsigned dma_voffset(int wave, int j, int lane, int64_t ld, int x0, int xdim) {
+  const int q = (wave * 2 + j) * 64 + lane;   // 16-B slot inside the 8 KiB tile
   if (!TR) {
-    int r = x0 + (lane & 15);
-    int kc = s * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(lds + lds_off_rowmajor(r, kc));
+    const int row = q >> 2, c = (q & 3) ^ swz_row(row);
+    if (x0 + row >= xdim) return 0x80000000u;
+    return (unsigned)(((int64_t)(x0 + row) * ld + c * 8) * 2);
   } else {
-    int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-    int kk = s * 32 + 8 * g + q;
-    int f = x0 >> 4;
-    int off = kk * 256 + ((f ^ tr_key(kk)) << 5) + ((p >> 1) << 4) + ((p & 1) << 3);
+    const int kk = q >> 4, cp = q & 15;
+    const int c16 = ((((cp >> 1) ^ tr_key(kk))) << 1) | (cp & 1);
+    if (x0 + c16 * 8 >= xdim) return 0x80000000u;
+    return (unsigned)(((int64_t)kk * ld + x0 + c16 * 8) * 2);
+  }
+}
+
+template <bool TR>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int x0, int lane) {
+  if (!TR) {
+    const int r = x0 + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(lds + r * 64 + ((((lane >> 4)) ^ swz_row(r)) << 4));
+  } else {
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int kk = 8 * g + q, f = x0 >> 4;
+    const int off = kk * 256 + ((f ^ tr_key(kk)) << 5) + ((p >> 1) << 4) + ((p & 1) << 3);
     typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(lds + off));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(lds + off + 4 * 256));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(lds + off + 4 * 256));   // key(kk+4) == key(kk)
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -96,8 +108,9 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int x0, int s, int 
 
 template <bool A_TR, bool B_TR, typename TC>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A tile + B tile) = 64 KiB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NSTAGE x (A tile + B tile) = 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
   // XCD-aware tile order: blocks that share an XCD (bid % 8) walk consecutive logical ids, and
@@ -112,11 +125,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int i0 = tile_m * BM, j0 = tile_n * BN;
 
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
   const int nk_total = (p.K + BK - 1) / BK;
   const int kt_begin = blockIdx.z * p.ktiles_per_split;
   const int kt_end = min(nk_total, kt_begin + p.ktiles_per_split);
+  const int nkt = kt_end - kt_begin;
+
+  // buffer descriptors: the hardware range check zero-fills rows past M/N and, for transposed
+  // operands, k rows past K
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  unsigned va[2], vb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    va[j] = dma_voffset<A_TR>(wave, j, lane, p.lda, i0, p.M);
+    vb[j] = dma_voffset<B_TR>(wave, j, lane, p.ldb, j0, p.N);
+  }
+  // per-k-tile advance: K-contiguous operands move by BK elements (scalar offset), transposed
+  // operands by BK rows (added to the per-lane offset so that the range check sees it)
+  const unsigned a_step = A_TR ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
+  const unsigned b_step = B_TR ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
+
+  auto issue = [&](int t) {   // k-tile index relative to kt_begin -> ring stage t & 3
+    char* st = smem + (t & (NSTAGE - 1)) * STAGE_BYTES + (wave * 2) * 1024;
+    const unsigned ka = (unsigned)(kt_begin + t) * a_step, kb = (unsigned)(kt_begin + t) * b_step;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j] + ka, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j], ka, 0, 0);
+      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + TILE_BYTES + j * 1024), 16, vb[j] + kb, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + TILE_BYTES + j * 1024), 16, vb[j], kb, 0, 0);
+    }
+  };
 
   f32x4 acc[4][4];  // [j frag][i frag]
 #pragma unroll
@@ -124,46 +163,33 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[4], rb[4];
-  if (kt_begin < kt_end) {
-    load_tile_global<A_TR>(A, p.lda, i0, p.M, kt_begin * BK, p.K, tid, ra);
-    load_tile_global<B_TR>(B, p.ldb, j0, p.N, kt_begin * BK, p.K, tid, rb);
-    store_tile_lds<A_TR>(smem, tid, ra);
-    store_tile_lds<B_TR>(smem + TILE_BYTES, tid, rb);
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = (kt + 1 < kt_end);
-    if (more) {
-      load_tile_global<A_TR>(A, p.lda, i0, p.M, (kt + 1) * BK, p.K, tid, ra);
-      load_tile_global<B_TR>(B, p.ldb, j0, p.N, (kt + 1) * BK, p.K, tid, rb);
-    }
-    const char* la = smem + cur * 2 * TILE_BYTES;
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t)
+    if (t < nkt) issue(t);
+
+  for (int t = 0; t < nkt; ++t) {
+    // tile t has landed once at most the DMAs of the (<= 2) younger tiles are outstanding
+    const int younger = nkt - 1 - t;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // every wave's DMAs for tile t are in LDS; stage (t-1)&3 is free
+    if (t + NSTAGE - 1 < nkt) issue(t + NSTAGE - 1);
+    const char* la = smem + (t & (NSTAGE - 1)) * STAGE_BYTES;
     const char* lb = la + TILE_BYTES;
+    bf16x8 fa[4], fb[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        fa[f] = read_frag<A_TR>(la, wm * 64 + f * 16, s, lane);
-        fb[f] = read_frag<B_TR>(lb, wn * 64 + f * 16, s, lane);
-      }
-#pragma unroll
-      for (int fj = 0; fj < 4; ++fj)
-#pragma unroll
-        for (int fi = 0; fi < 4; ++fi)
-          // D rows <- B operand (j), D cols <- A operand (i): each lane ends up with 4
-          // consecutive j of one row i, i.e. a contiguous 8/16-byte piece of C.
-          acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[fj], fa[fi], acc[fj][fi], 0, 0, 0);
+    for (int f = 0; f < 4; ++f) {
+      fa[f] = read_frag<A_TR>(la, wm * 64 + f * 16, lane);
+      fb[f] = read_frag<B_TR>(lb, wn * 64 + f * 16, lane);
     }
-    if (more) {
-      char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      store_tile_lds<A_TR>(na, tid, ra);
-      store_tile_lds<B_TR>(na + TILE_BYTES, tid, rb);
-    }
-    __syncthreads();
-    cur ^= 1;
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+      for (int fi = 0; fi < 4; ++fi)
+        // D rows <- B operand (j), D cols <- A operand (i): each lane ends up with 4 consecutive
+        // j of one row i, i.e. a contiguous 8/16-byte piece of C.
+        acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[fj], fa[fi], acc[fj][fi], 0, 0, 0);
   }
 
   // ---- epilogue -----------------------------------------------------------------------
@@ -189,8 +215,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         float4 a = make_float4(0, 0, 0, 0);
         if (p.epilogue == FCMF_EPI_GELU) { if (AUX) Vec4<TC>::store(AUX + off, v); }
         else if (p.epilogue != FCMF_EPI_TANH) a = Vec4<TC>::load(AUX + off);
-        v.x = apply_epilogue(v.x, p.epilogue, a.x); v.y = apply_epilogue(v.y, p.epilogue, a.y);
-        v.z = apply_epilogue(v.z, p.epilogue, a.z); v.w = apply_epilogue(v.w, p.epilogue, a.w);
+        if constexpr (sizeof(TC) == 2) {
+          v.x = apply_epilogue_fast(v.x, p.epilogue, a.x); v.y = apply_epilogue_fast(v.y, p.epilogue, a.y);
+          v.z = apply_epilogue_fast(v.z, p.epilogue, a.z); v.w = apply_epilogue_fast(v.w, p.epilogue, a.w);
+        } else {
+          v.x = apply_epilogue(v.x, p.epilogue, a.x); v.y = apply_epilogue(v.y, p.epilogue, a.y);
+          v.z = apply_epilogue(v.z, p.epilogue, a.z); v.w = apply_epilogue(v.w, p.epilogue, a.w);
+        }
       }
       if constexpr (sizeof(TC) == 4) {
         float* cf = reinterpret_cast<float*>(C) + off;
@@ -296,21 +327,41 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GenericParams p) {
 }
 
 // column sums ----------------------------------------------------------------------------
+// block = 256 columns x rows_per_block rows: lane -> 4 adjacent columns (8/16-byte loads, a wave
+// reads 256 contiguous columns), the 4 waves stride the rows; LDS tree over the waves, then one
+// float atomic per column per block.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ out, int M, int N,
-                                                     int64_t ldx, int rows_per_block) {
-  // block (bx, by): columns [bx*64, +64), rows [by*rows_per_block, ...); 4 waves split the rows
-  __shared__ float red[4][64];
+                                                     int64_t ldx, int rows_per_block, int vec) {
+  __shared__ float4 red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+  const int col = blockIdx.x * 256 + lane * 4;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
-  float s = 0.f;
-  if (col < N)
-    for (int r = r0 + wave; r < r1; r += 4) s += to_f32<T>(X[(int64_t)r * ldx + col]);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec && col + 3 < N) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const float4 v = Vec4<T>::load(X + (int64_t)r * ldx + col);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  } else if (col < N) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const T* p = X + (int64_t)r * ldx + col;
+      s.x += to_f32<T>(p[0]);
+      if (col + 1 < N) s.y += to_f32<T>(p[1]);
+      if (col + 2 < N) s.z += to_f32<T>(p[2]);
+      if (col + 3 < N) s.w += to_f32<T>(p[3]);
+    }
+  }
   red[wave][lane] = s;
   __syncthreads();
-  if (wave == 0 && col < N) atomicAdd(out + col, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+  if (wave == 0 && col < N) {
+    const float4 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
+    atomicAdd(out + col, a.x + b.x + c.x + d.x);
+    if (col + 1 < N) atomicAdd(out + col + 1, a.y + b.y + c.y + d.y);
+    if (col + 2 < N) atomicAdd(out + col + 2, a.z + b.z + c.z + d.z);
+    if (col + 3 < N) atomicAdd(out + col + 3, a.w + b.w + c.w + d.w);
+  }
 }
 
 // =========================================================================================
@@ -318,7 +369,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
 // =========================================================================================
 template <bool A_TR, bool B_TR>
 static int launch_bf16(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st) {
-  size_t smem = 4 * TILE_BYTES;
+  size_t smem = NSTAGE * STAGE_BYTES;
   if (out_dtype == FCMF_F32) {
     auto k = gemm_bf16_kernel<A_TR, B_TR, float>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -348,16 +399,22 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
   const int a_contig = trans_a ? M : K, b_contig = trans_b ? N : K;
   const bool fast = in_dtype == FCMF_BF16 && al16(A) && al16(B) && al16(C) && (!aux || al16(aux)) &&
                     (!bias || al16(bias)) && (lda % 8 == 0) && (ldb % 8 == 0) && (a_contig % 8 == 0) &&
-                    (b_contig % 8 == 0) && (N % 4 == 0) && (ldc % 4 == 0) && K > 0;
+                    (b_contig % 8 == 0) && (N % 4 == 0) && (ldc % 4 == 0) && K > 0 &&
+                    // K-contiguous operands cannot zero-fill a partial k-tile; 32-bit byte offsets
+                    (trans_a || K % BK == 0) && (trans_b || K % BK == 0) &&
+                    (((int64_t)(trans_a ? K : M) * lda) < (1ll << 30)) && (((int64_t)(trans_b ? K : N) * ldb) < (1ll << 30));
   if (fast) {
-    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0};
+    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0};
+    // bytes addressable through each operand: (rows - 1) * ld + contiguous extent
+    p.a_bytes = (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
+    p.b_bytes = (unsigned)((((int64_t)(trans_b ? K : N) - 1) * ldb + (trans_b ? N : K)) * 2);
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int nk = (K + BK - 1) / BK;
     int ksplit = 1;
     // split K only where the output grid cannot fill the chip and C is an f32 accumulator
     // (weight gradients: K = number of tokens).
     if (accumulate && epilogue == FCMF_EPI_NONE && tiles < 512) {
-      ksplit = (768 + tiles - 1) / tiles;
+      ksplit = 512 / tiles;   // one round of <= 512 resident blocks (256 CUs x 2)
       if (ksplit > nk / 4) ksplit = nk / 4 > 0 ? nk / 4 : 1;
       if (ksplit > 32) ksplit = 32;
     }
@@ -392,10 +449,11 @@ extern "C" int fcmf_colsum(const void* X, float* out, int M, int N, int64_t ldx,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!accumulate) { if (hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) return FCMF_ERR_LAUNCH; }
   if (M == 0) return FCMF_OK;
-  int rpb = 512;
-  dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
-  if (dtype == FCMF_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)X, out, M, N, ldx, rpb);
-  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)X, out, M, N, ldx, rpb);
+  const int vec = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  int rpb = 256;
+  dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)X, out, M, N, ldx, rpb, vec);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)X, out, M, N, ldx, rpb, vec);
   else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;

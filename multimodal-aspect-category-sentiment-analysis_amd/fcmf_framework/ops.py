@@ -436,6 +436,9 @@ def _chk_same_layout(a, b):
         raise H.HipLibraryError("attention: K and V of a segment must share shape and strides")
 
 
+USE_MFMA_ATTENTION = True   # tests flip this to compare the MFMA kernel with the VALU kernel
+
+
 class AttentionFn(torch.autograd.Function):
     """Two-segment multi-head attention (see fcmf_attn_desc in include/fcmf_hip.h).
       q  [G,R,heads*d]; k1/v1 [G,T1,heads*d] shared by the R rows of a group;
@@ -459,10 +462,19 @@ class AttentionFn(torch.autograd.Function):
         G, R, HD = q.shape
         out = torch.empty((G, R, HD), dtype=q.dtype, device=q.device)
         lse = torch.empty((G, heads, R), dtype=torch.float32, device=q.device)
-        a = _desc(q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal, 0)
-        H.check(H.lib().fcmf_attn_small_fwd(a, H.ptr(out), H.ptr(lse), H.stream()), "fcmf_attn_small_fwd")
+        # text-encoder shape (bf16, head dim 64, <=128 keys, plain mask): MFMA kernel
+        mfma = (q.dtype == torch.bfloat16 and HD // heads == 64 and k2 is None and bias is None and not causal
+                and k1 is not None and k1.shape[1] <= 128 and R <= 128 and q.is_contiguous() and k1.is_contiguous()
+                and v1.is_contiguous() and USE_MFMA_ATTENTION)
+        if mfma:
+            H.check(H.lib().fcmf_attn_mfma_fwd(H.ptr(q), H.ptr(k1), H.ptr(v1), H.ptr(mask), H.ptr(out), H.ptr(lse), G, heads,
+                                               R, k1.shape[1], HD, HD, HD, scale, p, seed, H.stream()), "fcmf_attn_mfma_fwd")
+        else:
+            a = _desc(q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal, 0)
+            H.check(H.lib().fcmf_attn_small_fwd(a, H.ptr(out), H.ptr(lse), H.stream()), "fcmf_attn_small_fwd")
         ctx.save_for_backward(q, k1, v1, k2, v2, mask, bias, out, lse)
         ctx.cfg = (heads, group_div, scale, p, seed, causal)
+        ctx.mfma = mfma
         return out
 
     @staticmethod
@@ -471,6 +483,12 @@ class AttentionFn(torch.autograd.Function):
         heads, group_div, scale, p, seed, causal = ctx.cfg
         G, R, HD = q.shape
         dout = dout.contiguous()
+        if ctx.mfma:
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k1), torch.empty_like(v1)
+            H.check(H.lib().fcmf_attn_mfma_bwd(H.ptr(q), H.ptr(k1), H.ptr(v1), H.ptr(mask), H.ptr(out), H.ptr(dout),
+                                               H.ptr(lse), H.ptr(dq), H.ptr(dk), H.ptr(dv), G, heads, R, k1.shape[1], HD, HD,
+                                               HD, scale, p, seed, H.stream()), "fcmf_attn_mfma_bwd")
+            return dq, dk, dv, None, None, None, None, None, None, None, None, None, None
         T1 = 0 if k1 is None else k1.shape[1]
         nch = max(1, (T1 + 127) // 128)
         dq = torch.empty((nch, G, R, HD), dtype=q.dtype, device=q.device)   # one partial per 128-key chunk

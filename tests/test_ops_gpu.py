@@ -380,3 +380,40 @@ def test_bertadam_matches_golden(dev):
         opt.step()
         assert max_err(p, torch.from_numpy(z["traj"][i])) < 1e-6
         assert abs(opt.get_lr()[0] - z["lrs"][i]) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Tq,Tk", [(128, 128), (77, 128), (128, 50), (33, 17)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attention_mfma_matches_reference_and_valu_kernel(dev, Tq, Tk, p):
+    """bf16 / head-dim-64 text-encoder attention on the MFMA kernel: against the fp64 reference
+    (p = 0) and against the VALU kernel with the SAME dropout seed (identical masks by construction)"""
+    from fcmf_framework import ops
+    G, heads, d = 3, 2, 64
+    HD = heads * d
+    mk = lambda shape, s: _rand(shape, dev, torch.bfloat16, 0.8, seed=s)
+    q0, k0, v0 = mk((G, Tq, HD), 1), mk((G, Tk, HD), 2), mk((G, Tk, HD), 3)
+    m01 = (torch.rand(G, Tk, generator=torch.Generator().manual_seed(7)) > 0.25).float()
+    m01[:, 0] = 1
+    mask = ((1 - m01) * torch.finfo(torch.float32).min).to(dev)
+    w = mk((G, Tq, HD), 9)
+    res = {}
+    for use in (True, False):
+        ops.USE_MFMA_ATTENTION = use
+        try:
+            q, k, v = (t.clone().requires_grad_(True) for t in (q0, k0, v0))
+            ops.manual_seed(5)
+            out = ops.attention(q, k, v, mask=mask, heads=heads, p=p, training=p > 0)
+            (out.float() * w.float()).sum().backward()
+            res[use] = (out.detach(), q.grad, k.grad, v.grad)
+        finally:
+            ops.USE_MFMA_ATTENTION = True
+    for a, b, name in zip(res[True], res[False], ("out", "dq", "dk", "dv")):
+        assert rel_err(a, b) < 3e-2, name
+    if p == 0.0:
+        c = lambda t: t.detach().double().cpu().requires_grad_(True)
+        qr, kr, vr = c(q0), c(k0), c(v0)
+        ref = _attn_ref(qr, kr, vr, None, None, mask.double().cpu(), None, heads, 1, 1 / math.sqrt(d))
+        (ref * w.double().cpu()).sum().backward()
+        for a, b, name in zip(res[True], (ref, qr.grad, kr.grad, vr.grad), ("out", "dq", "dk", "dv")):
+            assert rel_err(a, b) < 3e-2, name

@@ -122,7 +122,8 @@ def test_tiny_fp32_grads_and_adamw_step_match_reference(tiny, dev):
             # elements whose gradient is ~0 get a +-lr update decided by rounding noise: compare where |ref g| is sane
             gref = torch.from_numpy(z["g_" + n]).abs()
             ok = gref > 1e-6 * gref.max()
-            assert (d[ok] - ref[ok]).abs().max().item() < 5e-3 * ref.abs().max().item(), n
+            # deltas are differences of fp32 parameters: allow a few ulps of |p| (~2e-9 at |p|~0.02) on top
+            assert (d[ok] - ref[ok]).abs().max().item() < 5e-3 * ref.abs().max().item() + 2e-8, n
     model.load_state_dict(P)
 
 

@@ -1,0 +1,64 @@
+// Standalone GEMM micro-benchmark over the FCMF step's shapes (links libfcmf_hip.so).
+//   hipcc -O2 tools/gemm_bench.cpp -Iinclude -L<pkg>/fcmf_framework -lfcmf_hip -o gpurun_out/gemm_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "fcmf_hip.h"
+
+struct Shape { const char* name; int M, N, K, ta, tb, epi, acc, out_f32; };
+
+static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
+
+int main(int argc, char** argv) {
+  int reps = argc > 1 ? atoi(argv[1]) : 20;
+  const int T = 49152;
+  std::vector<Shape> shapes = {
+      {"fwd  qkv/out   NT 49152x768x768", T, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"fwd  ffn1+gelu NT 49152x3072x768", T, 3072, 768, 0, 0, FCMF_EPI_GELU, 0, 0},
+      {"fwd  ffn1 noepi NT 49152x3072x768", T, 3072, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"fwd  ffn2      NT 49152x768x3072", T, 768, 3072, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"dX   out       NN 49152x768x768", T, 768, 768, 0, 1, FCMF_EPI_NONE, 0, 0},
+      {"dX   ffn2+dgelu NN 49152x3072x768", T, 3072, 768, 0, 1, FCMF_EPI_DGELU, 0, 0},
+      {"dX   ffn1      NN 49152x768x3072", T, 768, 3072, 0, 1, FCMF_EPI_NONE, 0, 0},
+      {"dW   768x768   TN k=49152", 768, 768, T, 1, 1, FCMF_EPI_NONE, 1, 1},
+      {"dW   3072x768  TN k=49152", 3072, 768, T, 1, 1, FCMF_EPI_NONE, 1, 1},
+      {"dW   768x3072  TN k=49152", 768, 3072, T, 1, 1, FCMF_EPI_NONE, 1, 1},
+      {"fwd  vismap    NT 21952x768x2048", 21952, 768, 2048, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"sq   NT 4096^3", 4096, 4096, 4096, 0, 0, FCMF_EPI_NONE, 0, 0},
+  };
+  size_t maxA = (size_t)T * 3072, maxB = (size_t)T * 3072, maxC = (size_t)T * 3072;
+  unsigned short *A, *B; void *C, *AUX; float* bias;
+  hipMalloc(&A, maxA * 2); hipMalloc(&B, maxB * 2); hipMalloc(&C, maxC * 4); hipMalloc(&AUX, maxC * 2); hipMalloc(&bias, 4096 * 4);
+  {
+    std::vector<unsigned short> h(maxA);
+    unsigned s = 12345;
+    for (auto& x : h) { s = s * 1664525u + 1013904223u; x = f2bf(((s >> 8) & 0xFFFF) / 32768.0f - 1.0f); }
+    hipMemcpy(A, h.data(), maxA * 2, hipMemcpyHostToDevice);
+    for (auto& x : h) { s = s * 1664525u + 1013904223u; x = f2bf((((s >> 8) & 0xFFFF) / 32768.0f - 1.0f) * 0.05f); }
+    hipMemcpy(B, h.data(), maxB * 2, hipMemcpyHostToDevice);
+    hipMemcpy(AUX, h.data(), maxA * 2, hipMemcpyHostToDevice);
+    hipMemset(bias, 0, 4096 * 4);
+    hipMemset(C, 0, maxC * 4);
+  }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (auto& sh : shapes) {
+    int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.N : sh.K, ldc = sh.N;
+    auto run = [&]() {
+      return fcmf_gemm(A, B, C, sh.acc ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU) ? AUX : nullptr,
+                       sh.M, sh.N, sh.K, lda, ldb, ldc, sh.ta, sh.tb, FCMF_BF16, sh.out_f32 ? FCMF_F32 : FCMF_BF16, sh.epi, sh.acc, nullptr);
+    };
+    int rc = run(); rc |= run();
+    hipDeviceSynchronize();
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps; ++i) run();
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    double tf = 2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12;
+    printf("%-40s rc=%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 2500)\n", sh.name, rc, ms, tf, tf / 25.0);
+  }
+  return 0;
+}
