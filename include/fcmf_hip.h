@@ -59,6 +59,9 @@ int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* au
               int trans_a, int trans_b, int in_dtype, int out_dtype,
               int epilogue, int accumulate, void* stream);
 
+/* tuning hook for benchmarks/tests: 0 = built-in heuristic, 128 / 256 = force that block tile */
+void fcmf_gemm_force_tile(int tile);
+
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X dtype = dtype, out float32. */
 int fcmf_colsum(const void* X, float* out, int M, int N, int64_t ldx, int dtype,
                 int accumulate, void* stream);

@@ -242,6 +242,272 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // =========================================================================================
+// Large-tile variant for the big GEMMs of the step: 256x256 block tile, BK = 32, 8 waves (2 x 4,
+// 128x64 per wave = 32 accumulator fragments), the same 4-stage LDS-DMA ring (32 KiB per stage,
+// 128 KiB, one workgroup per CU).  Compared with the 128x128 kernel each MFMA needs 25% fewer LDS
+// fragment bytes (12 ds_read_b128 per 32 MFMAs) and half the DMA instructions, and the fragments of
+// k-tile t+1 are read into a second register set while the 32 MFMAs of k-tile t issue.
+// =========================================================================================
+constexpr int GB = 256;                       // block tile edge
+constexpr int BIG_TILE_BYTES = GB * BK * 2;   // 16 KiB per operand tile
+constexpr int BIG_STAGE_BYTES = 2 * BIG_TILE_BYTES;
+
+template <bool TR>
+__device__ __forceinline__ unsigned dma_voffset_big(int wave, int j, int lane, int64_t ld, int x0, int xdim) {
+  const int q = (wave * 2 + j) * 64 + lane;   // 16-B slot inside the 16 KiB tile (1024 slots)
+  if (!TR) {
+    const int row = q >> 2, c = (q & 3) ^ swz_row(row);
+    if (x0 + row >= xdim) return 0x80000000u;
+    return (unsigned)(((int64_t)(x0 + row) * ld + c * 8) * 2);
+  } else {
+    const int kk = q >> 5, cp = q & 31;        // 512-B rows: 32 chunks of 16 B
+    const int c16 = ((((cp >> 1) ^ tr_key(kk))) << 1) | (cp & 1);
+    if (x0 + c16 * 8 >= xdim) return 0x80000000u;
+    return (unsigned)(((int64_t)kk * ld + x0 + c16 * 8) * 2);
+  }
+}
+
+template <bool TR>
+__device__ __forceinline__ bf16x8 read_frag_big(const char* lds, int x0, int lane) {
+  if (!TR) {
+    const int r = x0 + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(lds + r * 64 + ((((lane >> 4)) ^ swz_row(r)) << 4));
+  } else {
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int kk = 8 * g + q, f = x0 >> 4;
+    const int off = kk * 512 + ((f ^ tr_key(kk)) << 5) + ((p >> 1) << 4) + ((p & 1) << 3);
+    typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(lds + off));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(lds + off + 4 * 512));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+template <bool A_TR, bool B_TR, typename TC>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 x 32 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;      // 2 x 4 waves: rows wm*128, cols wn*64
+
+  const int tiles_n = (p.N + GB - 1) / GB;
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int i0 = tile_m * GB, j0 = tile_n * GB;
+
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = blockIdx.z * p.ktiles_per_split;
+  const int kt_end = min(nk_total, kt_begin + p.ktiles_per_split);
+  const int nkt = kt_end - kt_begin;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  unsigned va[2], vb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    va[j] = dma_voffset_big<A_TR>(wave, j, lane, p.lda, i0, p.M);
+    vb[j] = dma_voffset_big<B_TR>(wave, j, lane, p.ldb, j0, p.N);
+  }
+  const unsigned a_step = A_TR ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
+  const unsigned b_step = B_TR ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
+
+  auto issue = [&](int t) {
+    char* st = smem + (t & (NSTAGE - 1)) * BIG_STAGE_BYTES + (wave * 2) * 1024;
+    const unsigned ka = (unsigned)(kt_begin + t) * a_step, kb = (unsigned)(kt_begin + t) * b_step;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j] + ka, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j], ka, 0, 0);
+      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + BIG_TILE_BYTES + j * 1024), 16, vb[j] + kb, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + BIG_TILE_BYTES + j * 1024), 16, vb[j], kb, 0, 0);
+    }
+  };
+  // Fragment pipeline (registers: B double-buffered, A in two halves):
+  //   phase 1 of tile t: read A_hi(t)                      | 16 MFMAs  A_lo(t) x B(t)
+  //   phase 2 of tile t: wait + barrier for tile t+1, DMA tile t+3,
+  //                      read A_lo(t+1)                    | 16 MFMAs  A_hi(t) x B(t)
+  //                      then read B(t+1)
+  // Per-lane LDS offsets are computed ONCE; fragment f of a K-contiguous operand is then a constant
+  // 1 KiB step away (row bit 3, which drives the swizzle, does not depend on f), so the reads of
+  // one operand share a base VGPR + immediate offsets.
+  typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+  const int rowl = lane & 15, g4 = lane >> 4, q4 = rowl >> 2, p4 = rowl & 3;
+  const int row_base = rowl * 64 + ((g4 ^ swz_row(rowl)) << 4);                       // K-contiguous image
+  const int tr_base = (8 * g4 + q4) * 512 + ((p4 >> 1) << 4) + ((p4 & 1) << 3);       // transposed image
+  const int trk = tr_key(8 * g4 + q4);
+  const int a_lane = A_TR ? tr_base : row_base + wm * 128 * 64;
+  const int b_lane = BIG_TILE_BYTES + (B_TR ? tr_base : row_base + wn * 64 * 64);
+  auto stage_ptr = [&](int t) { return smem + (t & (NSTAGE - 1)) * BIG_STAGE_BYTES; };
+  auto frag_a = [&](const char* st, int f) -> bf16x8 {     // f = 0..7 (16-row fragment of this wave's 128 rows)
+    if (!A_TR) return *reinterpret_cast<const bf16x8*>(st + a_lane + f * 1024);
+    const char* q = st + a_lane + (((wm * 8 + f) ^ trk) << 5);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * 512));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  };
+  auto frag_b = [&](const char* st, int f) -> bf16x8 {     // f = 0..3
+    if (!B_TR) return *reinterpret_cast<const bf16x8*>(st + b_lane + f * 1024);
+    const char* q = st + b_lane + (((wn * 4 + f) ^ trk) << 5);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * 512));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  };
+  auto load_a = [&](int t, int half, bf16x8 (&fa)[4]) {
+    const char* st = stage_ptr(t);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fa[f] = frag_a(st, half * 4 + f);
+  };
+  auto load_b = [&](int t, bf16x8 (&fb)[4]) {
+    const char* st = stage_ptr(t);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fb[f] = frag_b(st, f);
+  };
+
+  f32x4 acc[4][8];  // [j frag][i frag]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the accumulator index must be a compile-time constant (runtime-indexed arrays go to scratch)
+  auto mma_lo = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj)
+        acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[fj], fa[fi], acc[fj][fi], 0, 0, 0);
+  };
+  auto mma_hi = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj)
+        acc[fj][4 + fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[fj], fa[fi], acc[fj][4 + fi], 0, 0, 0);
+  };
+  // wait until k-tile `t` has landed: at most one younger tile (4 DMAs) may stay in flight
+  auto wait_tile = [&](int t) {
+    if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  // One register set per fragment group (acc 128 + 3 x 16 VGPRs): no unrolled double buffering, so
+  // the accumulators stay in place around the loop.
+  bf16x8 alo[4], ahi[4], bb[4];
+  if (nkt > 0) {
+    issue(0);
+    if (nkt > 1) issue(1);
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    if (nkt > 2) issue(2);
+    load_b(0, bb);
+    load_a(0, 0, alo);
+  }
+  for (int t = 0; t < nkt; ++t) {
+    load_a(t, 1, ahi);                 // streams in under the first 16 MFMAs
+    mma_lo(alo, bb);
+    if (t + 1 < nkt) {
+      wait_tile(t + 1);
+      __builtin_amdgcn_s_barrier();    // tile t+1 visible to all waves; stage (t+3)&3 free
+      if (t + 3 < nkt) issue(t + 3);
+      load_a(t + 1, 0, alo);           // streams in under the second 16 MFMAs
+    }
+    mma_hi(ahi, bb);
+    if (t + 1 < nkt) load_b(t + 1, bb);
+  }
+
+  // ---- epilogue: accumulators -> LDS (f32, one 128-row half at a time) -> row-wise output -----
+  // Fragment-layout stores touch 16 rows x 32 B per instruction and are store-issue bound; going
+  // through LDS every wave instruction writes (or atomically adds) whole 512-B / 256-B row pieces,
+  // and bias / GELU / gelu' / tanh' run on contiguous 8-element groups with coalesced aux accesses.
+  TC* C = reinterpret_cast<TC*>(p.C);
+  TC* AUX = reinterpret_cast<TC*>(p.aux);
+  const bool atomic = (p.ksplit > 1);
+  const bool lead = (blockIdx.z == 0);
+  float* Ct = reinterpret_cast<float*>(smem);   // [128][256] f32; 16-B chunk index XOR (row & 7)
+  __syncthreads();                              // every wave is done with the operand ring
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int fi = 0; fi < 8; ++fi) {
+        const int row = fi * 16 + (lane & 15);
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+          const int chunk = wn * 16 + fj * 4 + (lane >> 4);
+          *reinterpret_cast<f32x4*>(Ct + row * 256 + ((chunk ^ (row & 7)) << 2)) = acc[fj][fi];
+        }
+      }
+    }
+    __syncthreads();
+    if (atomic) {
+      // split-K partial: 256-B contiguous float atomics (one dword per lane, full-rate shape)
+      float* Cf = reinterpret_cast<float*>(C);
+      for (int it = 0; it < 16; ++it) {
+        const int row = wave * 16 + it, gi = i0 + half * 128 + row;
+        if (gi >= p.M) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int col = lane + 64 * k, gj = j0 + col;
+          if (gj < p.N) atomicAdd(Cf + (int64_t)gi * p.ldc + gj, Ct[row * 256 + ((((col >> 2)) ^ (row & 7)) << 2) + (col & 3)]);
+        }
+      }
+    } else {
+      for (int it = 0; it < 8; ++it) {
+        const int row = wave * 16 + it * 2 + (lane >> 5), gi = i0 + half * 128 + row;
+        const int c0 = (lane & 31) * 2, gj = j0 + c0 * 4;
+        if (gi >= p.M || gj >= p.N) continue;
+        float v[8];
+        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(Ct + row * 256 + ((c0 ^ (row & 7)) << 2));
+        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(Ct + row * 256 + (((c0 + 1) ^ (row & 7)) << 2));
+        if (p.bias && lead) {
+          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gj), b1 = *reinterpret_cast<const float4*>(p.bias + gj + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        const int64_t off = (int64_t)gi * p.ldc + gj;
+        if (p.epilogue != FCMF_EPI_NONE) {
+          float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (p.epilogue == FCMF_EPI_GELU) {
+            if (AUX) { Vec4<TC>::store(AUX + off, make_float4(v[0], v[1], v[2], v[3])); Vec4<TC>::store(AUX + off + 4, make_float4(v[4], v[5], v[6], v[7])); }
+          } else if (p.epilogue != FCMF_EPI_TANH) {
+            const float4 a0 = Vec4<TC>::load(AUX + off), a1 = Vec4<TC>::load(AUX + off + 4);
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = sizeof(TC) == 2 ? apply_epilogue_fast(v[e], p.epilogue, a[e]) : apply_epilogue(v[e], p.epilogue, a[e]);
+        }
+        if constexpr (sizeof(TC) == 4) {
+          float* cf = reinterpret_cast<float*>(C) + off;
+          if (p.accumulate) {
+            const float4 o0 = *reinterpret_cast<float4*>(cf), o1 = *reinterpret_cast<float4*>(cf + 4);
+            v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+          }
+          *reinterpret_cast<float4*>(cf) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(cf + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(C + off) = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =========================================================================================
 // generic kernel: C = op(A) op(B) with arbitrary element strides, f32 MFMA (exact fmaf chains)
 // =========================================================================================
 struct GenericParams {
@@ -383,6 +649,25 @@ static int launch_bf16(const GemmParams& p, int out_dtype, dim3 grid, hipStream_
   return FCMF_OK;
 }
 
+template <bool A_TR, bool B_TR>
+static int launch_bf16_big(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st) {
+  size_t smem = NSTAGE * BIG_STAGE_BYTES;
+  if (out_dtype == FCMF_F32) {
+    auto k = gemm_bf16_big_kernel<A_TR, B_TR, float>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+  } else {
+    auto k = gemm_bf16_big_kernel<A_TR, B_TR, bf16_t>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+  }
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced (benchmarks, tests)
+extern "C" void fcmf_gemm_force_tile(int tile) { g_force_tile = tile; }
+
 extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux, int M, int N, int K,
                          int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
                          int out_dtype, int epilogue, int accumulate, void* stream) {
@@ -408,8 +693,29 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     // bytes addressable through each operand: (rows - 1) * ld + contiguous extent
     p.a_bytes = (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
     p.b_bytes = (unsigned)((((int64_t)(trans_b ? K : N) - 1) * ldb + (trans_b ? N : K)) * 2);
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int nk = (K + BK - 1) / BK;
+    const int tiles_big = ((M + GB - 1) / GB) * ((N + GB - 1) / GB);
+    // 256x256 tiles once there is enough work to fill the chip with them (directly or through split-K)
+    bool big = M >= 256 && N >= 256 && ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && (int64_t)M * N * K >= (1ll << 33))) &&
+               (N % 8 == 0) && (ldc % 8 == 0);
+    if (g_force_tile == 128) big = false;
+    if (g_force_tile == 256) big = (N % 8 == 0) && (ldc % 8 == 0);
+    if (big) {
+      int ksplit = 1;
+      if (accumulate && epilogue == FCMF_EPI_NONE && tiles_big < 256) {
+        ksplit = 256 / tiles_big;
+        if (ksplit > nk / 8) ksplit = nk / 8 > 0 ? nk / 8 : 1;
+        if (ksplit > 64) ksplit = 64;
+      }
+      p.ktiles_per_split = (nk + ksplit - 1) / ksplit;
+      p.ksplit = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+      dim3 grid(tiles_big, 1, p.ksplit);
+      if (!trans_a && !trans_b) return launch_bf16_big<false, false>(p, out_dtype, grid, st);
+      if (!trans_a && trans_b) return launch_bf16_big<false, true>(p, out_dtype, grid, st);
+      if (trans_a && !trans_b) return launch_bf16_big<true, false>(p, out_dtype, grid, st);
+      return launch_bf16_big<true, true>(p, out_dtype, grid, st);
+    }
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int ksplit = 1;
     // split K only where the output grid cannot fill the chip and C is an f32 accumulator
     // (weight gradients: K = number of tokens).

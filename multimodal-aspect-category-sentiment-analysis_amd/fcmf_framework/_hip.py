@@ -36,6 +36,7 @@ SIGNATURES = {
     "fcmf_abi_version": [],
     "fcmf_build_info": [],
     "fcmf_gemm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_gemm_force_tile": [_i],
     "fcmf_colsum": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "fcmf_attn_small_fwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp],
     "fcmf_attn_small_bwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -82,7 +83,8 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args
-            fn.restype = ctypes.c_char_p if name == "fcmf_build_info" else ctypes.c_int
+            fn.restype = (ctypes.c_char_p if name == "fcmf_build_info" else
+                          None if name == "fcmf_gemm_force_tile" else ctypes.c_int)
         _lib = l
     return _lib
 

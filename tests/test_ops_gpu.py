@@ -43,6 +43,29 @@ def test_gemm_layouts(dev, dtype, ta, tb, M, N, K):
     assert rel_err(C, ref) < TOL[dtype], (ta, tb, M, N, K)
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(700, 520, 96), (256, 256, 32), (1000, 776, 224)])
+def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
+    """both MFMA kernels (128x128 and 256x256 block tiles) on ragged M/N edges and odd k-tile counts"""
+    ops, H = _ops()
+    A = _rand((K, M) if ta else (M, K), dev, torch.bfloat16, seed=1)
+    B = _rand((K, N) if tb else (N, K), dev, torch.bfloat16, seed=2)
+    bias = _rand((N,), dev, seed=3)
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    H.lib().fcmf_gemm_force_tile(tile)
+    try:
+        ops.gemm(A, B, C, M, N, K, A.shape[1], B.shape[1], N, ta, tb, bias=bias)
+        Cf = torch.full((M, N), 0.5, dtype=torch.float32, device=dev)
+        ops.gemm(A, B, Cf, M, N, K, A.shape[1], B.shape[1], N, ta, tb, acc=True)
+    finally:
+        H.lib().fcmf_gemm_force_tile(0)
+    Af = A.float().cpu().t() if ta else A.float().cpu()
+    Bf = B.float().cpu() if tb else B.float().cpu().t()
+    assert rel_err(C, Af @ Bf + bias.cpu()) < 2e-2
+    assert rel_err(Cf, Af @ Bf + 0.5) < 1e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(dev, dtype):
     ops, H = _ops()

@@ -13,6 +13,9 @@ static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFF
 
 int main(int argc, char** argv) {
   int reps = argc > 1 ? atoi(argv[1]) : 20;
+  int tile = argc > 2 ? atoi(argv[2]) : 0;
+  fcmf_gemm_force_tile(tile);
+  printf("---- forced tile: %d (0 = heuristic)\n", tile);
   const int T = 49152;
   std::vector<Shape> shapes = {
       {"fwd  qkv/out   NT 49152x768x768", T, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
