@@ -36,6 +36,7 @@ class GradReducer:
         self._work = []
         self._hooks = []
         self._stream = None
+        self.enabled = True        # set False on non-boundary micro-steps of gradient accumulation
         if self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -49,6 +50,8 @@ class GradReducer:
 
     # -- called by autograd right after p.grad has been accumulated ------------------------------
     def _on_grad(self, p):
+        if not self.enabled:
+            return
         bi = self._bucket_of[id(p)]
         if id(p) in self._ready[bi]:
             return

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""IAOG seq2seq pre-training driver on MI355X -- drop-in for the reference's run_pretraining_fcmf.py.
+
+Same flags (reference run_pretraining_fcmf.py:45-84), same step (:284-337: FCMFSeq2Seq forward,
+CE(ignore_index=-100) over [B,V,Ld], clip 1.0, AdamW (wd 1e-5 / 0, eps=--adam_epsilon), linear
+schedule), same per-epoch checkpoint dict (:27-42,455-460).  Reference behaviours kept on purpose:
+`model.decoder.embedding` is re-created after construction (:189), which un-ties it from the
+encoder's word embeddings while `decoder.dense.weight` stays tied to them.
+Extra flags: --bf16, --synthetic_steps N (seeded synthetic batches, precomputed features).
+With real data the driver imports the user's `iaog_dataset.IAOGDataset` (host-side producer,
+SURVEY.md section 8(f) "next") and torchvision, as the reference does.
+"""
+import argparse
+import logging
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+from fcmf_framework import ops  # noqa: E402
+from fcmf_framework.dp import GradReducer  # noqa: E402
+from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq  # noqa: E402
+from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup  # noqa: E402
+
+
+def save_model(path, model, optimizer, scheduler, epoch, best_score=0.0):
+    m = model.module if hasattr(model, 'module') else model
+    torch.save({'epoch': epoch, 'best_score': best_score, 'model_state_dict': m.state_dict(),
+                'optimizer_state_dict': optimizer.state_dict(), 'scheduler_state_dict': scheduler.state_dict()}, path)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--data_dir", default='../iaog-dataset', type=str)
+    p.add_argument("--pretrained_data_dir", default='../vimacsa', type=str)
+    p.add_argument("--output_dir", default=None, type=str, required=True)
+    p.add_argument('--image_dir', default='../vimacsa/image')
+    p.add_argument("--pretrained_hf_model", default=None, type=str, required=True)
+    p.add_argument("--resume_from_checkpoint", default=None, type=str)
+    p.add_argument("--num_imgs", default=7, type=int)
+    p.add_argument("--num_rois", default=4, type=int)
+    p.add_argument("--max_len_decoder", default=20, type=int)
+    p.add_argument("--do_train", action='store_true')
+    p.add_argument("--do_eval", action='store_true')
+    p.add_argument("--train_batch_size", default=16, type=int)
+    p.add_argument("--eval_batch_size", default=16, type=int)
+    p.add_argument("--learning_rate", default=3e-5, type=float)
+    p.add_argument("--adam_epsilon", default=1e-8, type=float)
+    p.add_argument("--num_train_epochs", default=8.0, type=float)
+    p.add_argument("--warmup_proportion", default=0.1, type=float)
+    p.add_argument('--gradient_accumulation_steps', type=int, default=1)
+    p.add_argument('--seed', type=int, default=42)
+    p.add_argument('--fp16', action='store_true')
+    p.add_argument('--alpha', type=float, default=1)
+    p.add_argument('--fine_tune_cnn', action='store_true')
+    p.add_argument("--no_cuda", action='store_true')
+    p.add_argument("--ddp", action='store_true')
+    p.add_argument("--local_rank", type=int, default=-1)
+    p.add_argument('--bf16', action='store_true')
+    p.add_argument('--synthetic_steps', type=int, default=0)
+    p.add_argument('--synthetic_dec_len', type=int, default=12)
+    p.add_argument('--vocab_size', type=int, default=0, help="decoder vocabulary (len(tokenizer) with real data)")
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.no_cuda or not torch.cuda.is_available():
+        raise SystemExit("run_pretraining_fcmf.py (MI355X build) has no CPU path: a ROCm GPU is required")
+    if args.ddp:
+        rank, local_rank, world = int(os.environ['RANK']), int(os.environ['LOCAL_RANK']), int(os.environ['WORLD_SIZE'])
+    else:
+        rank, local_rank, world = 0, 0, 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    master = rank == 0
+    random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed); ops.manual_seed(args.seed + rank)
+    if world > 1:
+        torch.distributed.init_process_group(backend='nccl', device_id=device)
+    logger = logging.getLogger("iaog")
+    if master:
+        os.makedirs(args.output_dir, exist_ok=True)
+        logger.setLevel(logging.INFO)
+        for h in (logging.FileHandler(f'{args.output_dir}/pretraining_iaog.log'), logging.StreamHandler()):
+            logger.addHandler(h)
+    ops.set_compute_dtype(torch.bfloat16 if (args.bf16 or args.fp16) else torch.float32)
+
+    tokenizer = None
+    if args.synthetic_steps <= 0:
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(args.pretrained_hf_model)
+    vocab = args.vocab_size or (len(tokenizer) if tokenizer is not None else 0)
+    if vocab <= 0:
+        from fcmf_framework.roberta import RobertaConfig
+        vocab = RobertaConfig.from_pretrained(args.pretrained_hf_model).vocab_size
+    model = FCMFSeq2Seq(vocab, args.max_len_decoder, args.pretrained_hf_model, args.num_imgs, args.num_rois, args.alpha)
+    model.decoder.embedding = torch.nn.Embedding(vocab, model.decoder.num_hiddens)       # reference :189
+    model = model.to(device)
+
+    no_decay = ['bias', 'LayerNorm.bias', 'LayerNorm.weight']
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    groups = [{'params': [p for n, p in named if not any(nd in n for nd in no_decay)], 'weight_decay': 1e-5},
+              {'params': [p for n, p in named if any(nd in n for nd in no_decay)], 'weight_decay': 0.0}]
+    optimizer = FusedAdamW(groups, lr=args.learning_rate, eps=args.adam_epsilon)
+
+    if args.synthetic_steps > 0:
+        import synthetic_data as synth
+        cfg = model.encoder.bert.cell.config
+        cfgd = dict(vocab_size=cfg.vocab_size, pad_token_id=cfg.pad_token_id)
+
+        def batches():
+            for i in range(args.synthetic_steps):
+                b = synth.synth_batch(args.train_batch_size, cfgd, S=min(128, cfg.max_position_embeddings - 2), num_imgs=args.num_imgs, num_roi=args.num_rois,
+                                      num_aspects=1, seed=args.seed + 1000 * rank + i, coord_dtype=torch.float32)
+                g = torch.Generator().manual_seed(args.seed + i)
+                dec = torch.randint(3, vocab, (args.train_batch_size, args.synthetic_dec_len), generator=g)
+                lab = torch.roll(dec, -1, dims=1)
+                lab[:, -1] = -100                                                           # iaog_dataset.py:93-96
+                yield (b["visual_embeds_att"], b["roi_embeds_att"], b["roi_coors"], b["input_ids"][:, 0],
+                       b["token_type_ids"][:, 0], b["attention_mask"][:, 0], b["added_attention_mask"][:, 0], dec, lab)
+        steps_per_epoch = args.synthetic_steps
+        make_loader = batches
+    else:
+        raise SystemExit("real-data IAOG pre-training needs the host-side producer (iaog_dataset.IAOGDataset + torchvision): "
+                         "SURVEY.md section 8(f) 'next'; use --synthetic_steps N for the kernel path")
+
+    num_train_steps = int(steps_per_epoch / args.gradient_accumulation_steps * args.num_train_epochs)
+    scheduler = get_linear_schedule_with_warmup(optimizer, int(num_train_steps * args.warmup_proportion), num_train_steps)
+    reducer = None
+    if world > 1:
+        reducer = GradReducer([p for n, p in named if "bert.cell.pooler" not in n])
+        reducer.broadcast_parameters(0)
+    start_epoch = 0
+    if args.resume_from_checkpoint and os.path.isfile(args.resume_from_checkpoint):
+        ck = torch.load(args.resume_from_checkpoint, map_location=device, weights_only=True)
+        model.load_state_dict(ck['model_state_dict'])
+        optimizer.load_state_dict(ck['optimizer_state_dict'])
+        scheduler.load_state_dict(ck['scheduler_state_dict'])
+        start_epoch = ck['epoch'] + 1
+
+    if args.do_train:
+        for epoch in range(start_epoch, int(args.num_train_epochs)):
+            model.train()
+            optimizer.zero_grad(set_to_none=True)
+            for step, batch in enumerate(make_loader()):
+                vis, roi, coors, enc_X, tt, am, added, dec_X, labels = (t.to(device) for t in batch)
+                logits = model(enc_X=enc_X, dec_X=dec_X, visual_embeds_att=vis, roi_embeds_att=roi, roi_coors=coors,
+                               token_type_ids=tt, attention_mask=am, added_attention_mask=added, source_valid_len=None,
+                               is_train=True)
+                loss = ops.cross_entropy(logits, labels, ignore_index=-100)                 # reference :322-324
+                if args.gradient_accumulation_steps > 1:
+                    loss = loss / args.gradient_accumulation_steps
+                boundary = (step + 1) % args.gradient_accumulation_steps == 0
+                if reducer is not None:
+                    reducer.enabled = boundary
+                loss.backward()
+                if boundary:
+                    if reducer is not None:
+                        reducer.finish()
+                    optimizer.step(max_grad_norm=1.0)
+                    scheduler.step()
+                    optimizer.zero_grad(set_to_none=True)
+                if master and step % 10 == 0:
+                    logger.info("epoch %d step %d loss %.4f", epoch, step, loss.item() * args.gradient_accumulation_steps)
+            if world > 1:
+                torch.distributed.barrier()
+            if master:
+                save_model(f'{args.output_dir}/seed_{args.seed}_iaog_model_last.pth', model, optimizer, scheduler, epoch)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
