@@ -37,6 +37,7 @@ extern "C" {
 #define FCMF_EPI_TANH 2   /* C = tanh(acc + bias)                                       */
 #define FCMF_EPI_DGELU 3  /* C = acc * gelu'(aux)      (aux = saved pre-activation)     */
 #define FCMF_EPI_DTANH 4  /* C = acc * (1 - aux^2)     (aux = saved tanh output)        */
+#define FCMF_EPI_ADD 5    /* C = acc + bias + aux      (residual-gradient accumulation)  */
 
 int fcmf_abi_version(void);
 /* human-readable "gfx950 ..." build string (host pointer, static storage) */
@@ -49,12 +50,14 @@ const char* fcmf_build_info(void);
  *   in_dtype: dtype of A and B; out_dtype: dtype of C and aux; bias is float32 or NULL.
  *   accumulate != 0 (out_dtype must be F32): C += result (split-K partials are added
  *   with float atomics, so C must be initialised).
+ *   colsum (float32 [N], may be NULL; not with accumulate): colsum[n] += sum_m C[m,n] -- the bias
+ *   gradient of the layer that produced the operand, fused into the epilogue.
  * Replaces nn.Linear forward/backward everywhere on the path: mm_modeling.py:182-184,
  * 229-231,272,308,320,422 ; fcmf_pretraining.py:25-26 ; roi_modeling.py:73 ;
  * fcmf_multimodal.py:18 and their autograd (dX = dY*W, dW = dY^T*X).
  * bf16 inputs whose contiguous dimensions are multiples of 8 elements with 16-byte aligned
  * bases run on the MFMA bf16 kernel; everything else runs on the generic f32-MFMA kernel. */
-int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux,
+int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
               int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
               int trans_a, int trans_b, int in_dtype, int out_dtype,
               int epilogue, int accumulate, void* stream);
@@ -132,10 +135,15 @@ int fcmf_add_ln_fwd(const void* x, const void* res, int64_t res_stride, const fl
                     int rows, int H, float eps, float dropout_p, uint64_t seed, int dtype,
                     void* stream);
 /* dz [rows,H] <- grad wrt (dropout(x)+res); dx (NULL when dropout_p==0: dx == dz) <- grad wrt x;
- * dgamma/dbeta float32 [H] are ACCUMULATED (atomics). */
+ * dgamma/dbeta float32 [H] are ACCUMULATED (atomics); dxsum (float32 [H], may be NULL) accumulates
+ * the column sums of dx = the bias gradient of the Linear that produced x. */
 int fcmf_add_ln_bwd(const void* dy, const void* z, const float* gamma, const float* mean,
-                    const float* rstd, void* dz, void* dx, float* dgamma, float* dbeta,
-                    int rows, int H, float dropout_p, uint64_t seed, int dtype, void* stream);
+                    const float* rstd, void* dz, void* dx, float* dgamma, float* dbeta, float* dxsum,
+                    float* workspace, int rows, int H, float dropout_p, uint64_t seed, int dtype,
+                    void* stream);
+/* floats of scratch `workspace` must hold (per-workgroup partial column sums, reduced by a second
+ * kernel without atomics); workspace == NULL falls back to float atomics. */
+int64_t fcmf_add_ln_bwd_workspace(int rows, int H);
 
 /* ---------------------------------------------------------------------------------------
  * RoBERTa embeddings (HF RobertaEmbeddings via mm_modeling.py:440-446).

@@ -13,26 +13,38 @@ struct GemmParams {
   int64_t lda, ldb, ldc;
   int epilogue, accumulate, ksplit, ktiles_per_split;
   unsigned a_bytes, b_bytes;   // extents of A / B for the buffer range check
+  float* colsum;               // optional: colsum[n] += sum_m C[m,n] (bias gradient of the producing layer)
+  int tiles, total_items;      // persistent big kernel: output tiles, tiles x k-splits
 };
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp + one v_exp + 6 FMAs instead of
-// the branchy libm erff.  Used only where the result is rounded to bf16 (8 significant bits).
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float y = 1.0f - poly * __expf(-ax * ax);
-  return copysignf(y, x);
+// bf16-output epilogues use odd minimax-style polynomials instead of erf/exp (no transcendental
+// issue slots): Phi(x) - 0.5 ~= x * P7(x^2) on |x| <= 4 (|err| <= 8e-5) and gelu'(x) - 0.5 ~= x * Q9(x^2)
+// on |x| <= 4.5 (|err| <= 3e-4), both far below bf16 resolution; saturated outside (tools: the fits
+// are reproduced by the snippet in DESIGN.md).  The f32 parity path keeps the exact erff forms.
+__device__ __forceinline__ float gelu_poly(float x) {
+  const float ax = fminf(fabsf(x), 4.0f), t = ax * ax;
+  float p = -1.992937524e-09f;
+  p = p * t + 1.462821838e-07f; p = p * t - 4.685912798e-06f; p = p * t + 8.774612016e-05f;
+  p = p * t - 1.093923500e-03f; p = p * t + 9.815655956e-03f; p = p * t - 6.639252684e-02f;
+  p = p * t + 3.989359758e-01f;
+  const float phi = 0.5f + copysignf(ax * p, x);
+  return x >= 4.0f ? x : (x <= -4.0f ? 0.0f : x * phi);
+}
+__device__ __forceinline__ float dgelu_poly(float x) {
+  const float ax = fminf(fabsf(x), 4.5f), t = ax * ax;
+  float p = -2.897521759e-11f;
+  p = p * t + 3.178414279e-09f; p = p * t - 1.532542835e-07f; p = p * t + 4.303428593e-06f;
+  p = p * t - 7.880709165e-05f; p = p * t + 1.000204828e-03f; p = p * t - 9.090597788e-03f;
+  p = p * t + 5.929092316e-02f; p = p * t - 2.656870675e-01f; p = p * t + 7.978704071e-01f;
+  return 0.5f + copysignf(ax * p, x);
 }
 __device__ __forceinline__ float apply_epilogue_fast(float v, int epi, float auxv) {
   switch (epi) {
-    case FCMF_EPI_GELU: return v * 0.5f * (1.0f + erf_fast(v * 0.70710678118654752440f));
+    case FCMF_EPI_GELU: return gelu_poly(v);
     case FCMF_EPI_TANH: return tanhf(v);
-    case FCMF_EPI_DGELU: {
-      const float cdf = 0.5f * (1.0f + erf_fast(auxv * 0.70710678118654752440f));
-      return v * (cdf + auxv * 0.39894228040143267794f * __expf(-0.5f * auxv * auxv));
-    }
+    case FCMF_EPI_DGELU: return v * dgelu_poly(auxv);
     case FCMF_EPI_DTANH: return v * (1.0f - auxv * auxv);
+    case FCMF_EPI_ADD: return v + auxv;
     default: return v;
   }
 }
@@ -43,6 +55,7 @@ __device__ __forceinline__ float apply_epilogue(float v, int epi, float auxv) {
     case FCMF_EPI_TANH: return tanhf(v);
     case FCMF_EPI_DGELU: return v * dgelu_f(auxv);
     case FCMF_EPI_DTANH: return v * (1.0f - auxv * auxv);
+    case FCMF_EPI_ADD: return v + auxv;
     default: return v;
   }
 }
@@ -197,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   TC* AUX = reinterpret_cast<TC*>(p.aux);
   const bool atomic = (p.ksplit > 1);
   const bool lead = (blockIdx.z == 0);
+  float4 cs[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
 #pragma unroll
   for (int fi = 0; fi < 4; ++fi) {
     const int i = i0 + wm * 64 + fi * 16 + (lane & 15);
@@ -236,6 +250,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         }
       } else {
         Vec4<TC>::store(C + off, v);
+      }
+      if (p.colsum) { cs[fj].x += v.x; cs[fj].y += v.y; cs[fj].z += v.z; cs[fj].w += v.w; }
+    }
+  }
+  if (p.colsum) {
+    // lanes that share (lane >> 4) hold the same 4 columns for 16 different rows: butterfly over lane & 15
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) {
+      float4 t = cs[fj];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64); t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
+      }
+      const int j = j0 + wn * 64 + fj * 16 + (lane >> 4) * 4;
+      if ((lane & 15) == 0 && j < p.N) {
+        atomicAdd(p.colsum + j, t.x); atomicAdd(p.colsum + j + 1, t.y); atomicAdd(p.colsum + j + 2, t.z); atomicAdd(p.colsum + j + 3, t.w);
       }
     }
   }
@@ -293,18 +323,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;      // 2 x 4 waves: rows wm*128, cols wn*64
 
+  // PERSISTENT workgroups: the grid is at most one workgroup per CU and each walks the work items
+  // (output tile x k-split) round by round.  Workgroups drift out of lockstep after the first round,
+  // so the HBM write bursts of the epilogues overlap other CUs' main loops instead of colliding.
+  // XCD-aware order inside a round: the workgroups of one XCD (blockIdx % 8) take consecutive
+  // logical items, and consecutive items share the A row-panel (all N tiles of one M tile) -> L2 hits.
   const int tiles_n = (p.N + GB - 1) / GB;
   const int nblk = gridDim.x;
-  int bid = blockIdx.x;
+  int slot = blockIdx.x;
   {
-    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    int q = nblk >> 3, r = nblk & 7, xcd = slot & 7, local = slot >> 3;
+    slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-  const int i0 = tile_m * GB, j0 = tile_n * GB;
-
   const int nk_total = (p.K + BK - 1) / BK;
-  const int kt_begin = blockIdx.z * p.ktiles_per_split;
+  for (int item = slot; item < p.total_items; item += nblk) {
+  const int zsplit = item / p.tiles, tile = item - zsplit * p.tiles;
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  const int i0 = tile_m * GB, j0 = tile_n * GB;
+  const int kt_begin = zsplit * p.ktiles_per_split;
   const int kt_end = min(nk_total, kt_begin + p.ktiles_per_split);
   const int nkt = kt_end - kt_begin;
 
@@ -433,9 +469,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
   TC* C = reinterpret_cast<TC*>(p.C);
   TC* AUX = reinterpret_cast<TC*>(p.aux);
   const bool atomic = (p.ksplit > 1);
-  const bool lead = (blockIdx.z == 0);
+  const bool lead = (zsplit == 0);
   float* Ct = reinterpret_cast<float*>(smem);   // [128][256] f32; 16-B chunk index XOR (row & 7)
   __syncthreads();                              // every wave is done with the operand ring
+  float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     if (wm == half) {
@@ -475,6 +512,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
           v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
         const int64_t off = (int64_t)gi * p.ldc + gj;
+        if (p.epilogue == 99) { if (v[0] == 123.456f) C[off] = from_f32<TC>(v[1]); continue; }   // timing probe: no stores
         if (p.epilogue != FCMF_EPI_NONE) {
           float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
           if (p.epilogue == FCMF_EPI_GELU) {
@@ -501,10 +539,34 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
           for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
           *reinterpret_cast<bf16x8*>(C + off) = o;
         }
+        if (p.colsum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[e] += v[e];
+        }
       }
     }
     __syncthreads();
   }
+  if (p.colsum) {
+    // a lane owns 8 fixed columns over 16 rows of the block tile; lanes l and l^32 share columns.
+    // Reduce the 8 waves through LDS first: ONE float atomic per column per workgroup (all row
+    // tiles of a column add to the same 256 addresses, so fewer, larger adds matter).
+    float* red = reinterpret_cast<float*>(smem);    // [8 waves][256]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = csum[e] + __shfl_xor(csum[e], 32, 64);
+      if (lane < 32) red[wave * 256 + lane * 8 + e] = t;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) t += red[w8 * 256 + tid];
+      if (j0 + tid < p.N) atomicAdd(p.colsum + j0 + tid, t);
+    }
+  }
+    __syncthreads();   // LDS (ring / staging) is reused by the next work item
+  }  // work items
 }
 
 // =========================================================================================
@@ -515,6 +577,7 @@ struct GenericParams {
   int M, N, K;
   int64_t a_si, a_sk, b_sj, b_sk, ldc;  // element strides: A(i,k) = A[i*a_si + k*a_sk]
   int epilogue, accumulate;
+  float* colsum;
 };
 
 template <typename TI, typename TC>
@@ -589,6 +652,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GenericParams p) {
         }
         if (p.accumulate) v += to_f32<TC>(C[off]);
         C[off] = from_f32<TC>(v);
+        if (p.colsum) atomicAdd(p.colsum + j, v);
       }
 }
 
@@ -665,16 +729,18 @@ static int launch_bf16_big(const GemmParams& p, int out_dtype, dim3 grid, hipStr
   return FCMF_OK;
 }
 
+static int g_num_cus = 256;    // MI355X: 8 XCDs x 32 CUs; one persistent 128-KiB-LDS workgroup per CU
 static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced (benchmarks, tests)
 extern "C" void fcmf_gemm_force_tile(int tile) { g_force_tile = tile; }
 
-extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux, int M, int N, int K,
-                         int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
+extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum, int M,
+                         int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
                          int out_dtype, int epilogue, int accumulate, void* stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0) return FCMF_ERR_ARG;
   if (M == 0 || N == 0) return FCMF_OK;
   if (accumulate && out_dtype != FCMF_F32) return FCMF_ERR_ARG;
-  if ((epilogue == FCMF_EPI_DGELU || epilogue == FCMF_EPI_DTANH) && !aux) return FCMF_ERR_ARG;
+  if ((epilogue == FCMF_EPI_DGELU || epilogue == FCMF_EPI_DTANH || epilogue == FCMF_EPI_ADD) && !aux) return FCMF_ERR_ARG;
+  if (colsum && accumulate) return FCMF_ERR_ARG;   // column sums are those of the final C, not of split-K partials
   if (in_dtype != FCMF_F32 && in_dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
   if (out_dtype != FCMF_F32 && out_dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -689,7 +755,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
                     (trans_a || K % BK == 0) && (trans_b || K % BK == 0) &&
                     (((int64_t)(trans_a ? K : M) * lda) < (1ll << 30)) && (((int64_t)(trans_b ? K : N) * ldb) < (1ll << 30));
   if (fast) {
-    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0};
+    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, colsum, 0, 0};
     // bytes addressable through each operand: (rows - 1) * ld + contiguous extent
     p.a_bytes = (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
     p.b_bytes = (unsigned)((((int64_t)(trans_b ? K : N) - 1) * ldb + (trans_b ? N : K)) * 2);
@@ -709,7 +775,9 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       }
       p.ktiles_per_split = (nk + ksplit - 1) / ksplit;
       p.ksplit = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
-      dim3 grid(tiles_big, 1, p.ksplit);
+      p.tiles = tiles_big;
+      p.total_items = tiles_big * p.ksplit;
+      dim3 grid(p.total_items < g_num_cus ? p.total_items : g_num_cus);
       if (!trans_a && !trans_b) return launch_bf16_big<false, false>(p, out_dtype, grid, st);
       if (!trans_a && trans_b) return launch_bf16_big<false, true>(p, out_dtype, grid, st);
       if (trans_a && !trans_b) return launch_bf16_big<true, false>(p, out_dtype, grid, st);
@@ -735,7 +803,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
   }
   GenericParams g{A, B, C, bias, aux, M, N, K,
                   trans_a ? 1 : lda, trans_a ? lda : 1, trans_b ? 1 : ldb, trans_b ? ldb : 1, ldc,
-                  epilogue, accumulate};
+                  epilogue, accumulate, colsum};
   dim3 grid((N + 63) / 64, (M + 63) / 64);
   if (in_dtype == FCMF_F32 && out_dtype == FCMF_F32)
     hipLaunchKernelGGL((gemm_generic_kernel<float, float>), grid, dim3(256), 0, st, g);

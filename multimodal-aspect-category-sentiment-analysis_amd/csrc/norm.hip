@@ -73,15 +73,16 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, T* __restrict__ dz,
                                                          T* __restrict__ dx, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, int rows, int H, float p,
+                                                         float* __restrict__ dbeta, float* __restrict__ dxsum,
+                                                         float* __restrict__ partial, int rows, int H, float p,
                                                          uint64_t seed) {
-  __shared__ float4 red[2][2][NP][64];
+  __shared__ float4 red[2][3][NP][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-  float4 ag[NP], ab[NP], gm[NP];
+  float4 ag[NP], ab[NP], gm[NP], ax[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
+    ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); ax[i] = make_float4(0, 0, 0, 0);
     const int c = (i * 64 + lane) * 4;
     gm[i] = c < H ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0, 0, 0, 0);
   }
@@ -120,6 +121,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
           o.z *= dropout_mult(seed, base + 2, p, inv_keep); o.w *= dropout_mult(seed, base + 3, p, inv_keep);
           Vec4<T>::store(dx + (int64_t)row * H + c, o);
         }
+        // column sums of the gradient that flows into the producing Linear = its bias gradient
+        ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
       }
     }
   }
@@ -129,15 +132,16 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
     const int half = step == 0 ? 2 : 1;
     if (w >= half && w < 2 * half) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) { red[w - half][0][i][lane] = ag[i]; red[w - half][1][i][lane] = ab[i]; }
+      for (int i = 0; i < NP; ++i) { red[w - half][0][i][lane] = ag[i]; red[w - half][1][i][lane] = ab[i]; red[w - half][2][i][lane] = ax[i]; }
     }
     __syncthreads();
     if (w < half) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
-        float4 a = red[w][0][i][lane], b = red[w][1][i][lane];
+        float4 a = red[w][0][i][lane], b = red[w][1][i][lane], c2 = red[w][2][i][lane];
         ag[i].x += a.x; ag[i].y += a.y; ag[i].z += a.z; ag[i].w += a.w;
         ab[i].x += b.x; ab[i].y += b.y; ab[i].z += b.z; ab[i].w += b.w;
+        ax[i].x += c2.x; ax[i].y += c2.y; ax[i].z += c2.z; ax[i].w += c2.w;
       }
     }
     __syncthreads();
@@ -147,12 +151,44 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
     for (int i = 0; i < NP; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < H) {
-        atomicAdd(dgamma + c + 0, ag[i].x); atomicAdd(dgamma + c + 1, ag[i].y);
-        atomicAdd(dgamma + c + 2, ag[i].z); atomicAdd(dgamma + c + 3, ag[i].w);
-        atomicAdd(dbeta + c + 0, ab[i].x); atomicAdd(dbeta + c + 1, ab[i].y);
-        atomicAdd(dbeta + c + 2, ab[i].z); atomicAdd(dbeta + c + 3, ab[i].w);
+        if (partial) {
+          // per-block partial sums [block][3][H]: no atomics; ln_partial_reduce_kernel finishes the sum
+          float* pb = partial + (int64_t)blockIdx.x * 3 * H + c;
+          *reinterpret_cast<float4*>(pb) = ag[i];
+          *reinterpret_cast<float4*>(pb + H) = ab[i];
+          *reinterpret_cast<float4*>(pb + 2 * H) = ax[i];
+        } else {
+          atomicAdd(dgamma + c + 0, ag[i].x); atomicAdd(dgamma + c + 1, ag[i].y);
+          atomicAdd(dgamma + c + 2, ag[i].z); atomicAdd(dgamma + c + 3, ag[i].w);
+          atomicAdd(dbeta + c + 0, ab[i].x); atomicAdd(dbeta + c + 1, ab[i].y);
+          atomicAdd(dbeta + c + 2, ab[i].z); atomicAdd(dbeta + c + 3, ab[i].w);
+          if (dxsum) {
+            atomicAdd(dxsum + c + 0, ax[i].x); atomicAdd(dxsum + c + 1, ax[i].y);
+            atomicAdd(dxsum + c + 2, ax[i].z); atomicAdd(dxsum + c + 3, ax[i].w);
+          }
+        }
       }
     }
+  }
+}
+
+// out[which][c] += sum_b partial[b][which][c]; one thread per (which, c), blocks strided by 8 row groups
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partial, int nblocks, int H,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float* __restrict__ dxsum) {
+  __shared__ float red[8][32];
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), which = blockIdx.y, part = threadIdx.x >> 5;
+  float s = 0.f;
+  if (col < H)
+    for (int b = part; b < nblocks; b += 8) s += partial[((int64_t)b * 3 + which) * H + col];
+  red[part][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (part == 0 && col < H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+    if (out) out[col] += t;
   }
 }
 
@@ -313,21 +349,29 @@ extern "C" int fcmf_add_ln_fwd(const void* x, const void* res, int64_t res_strid
   return FCMF_OK;
 }
 
+static int ln_bwd_blocks(int rows) {
+  int blocks = (rows + 3) / 4;
+  return blocks > 2048 ? 2048 : blocks;   // 8 waves per SIMD-quad keep enough rows in flight to reach the HBM rate
+}
+
+extern "C" int64_t fcmf_add_ln_bwd_workspace(int rows, int H) { return (int64_t)ln_bwd_blocks(rows) * 3 * H; }
+
 extern "C" int fcmf_add_ln_bwd(const void* dy, const void* z, const float* gamma, const float* mean, const float* rstd,
-                               void* dz, void* dx, float* dgamma, float* dbeta, int rows, int H, float dropout_p,
-                               uint64_t seed, int dtype, void* stream) {
+                               void* dz, void* dx, float* dgamma, float* dbeta, float* dxsum, float* workspace,
+                               int rows, int H, float dropout_p, uint64_t seed, int dtype, void* stream) {
   if (!dy || !z || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || rows < 0 || H <= 0) return FCMF_ERR_ARG;
   if (H % 4 != 0 || H > LN_MAXP * 256) return FCMF_ERR_UNSUPPORTED;
   if (dropout_p > 0.f && !dx) return FCMF_ERR_ARG;
   if (rows == 0) return FCMF_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  const int blocks = ln_bwd_blocks(rows);
   if (dtype != FCMF_F32 && dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
 #define LAUNCH_(T, NP) hipLaunchKernelGGL((add_ln_bwd_kernel<T, NP>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)z, \
-    gamma, mean, rstd, (T*)dz, (T*)(dropout_p > 0.f ? dx : nullptr), dgamma, dbeta, rows, H, dropout_p, seed)
+    gamma, mean, rstd, (T*)dz, (T*)(dropout_p > 0.f ? dx : nullptr), dgamma, dbeta, dxsum, workspace, rows, H, dropout_p, seed)
   LN_DISPATCH(dtype, H);
 #undef LAUNCH_
+  if (workspace)
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((H + 31) / 32, 3), dim3(256), 0, st, workspace, blocks, H, dgamma, dbeta, dxsum);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }

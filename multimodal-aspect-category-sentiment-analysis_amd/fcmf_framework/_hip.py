@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfcmf_hip.so")
 
 F32, BF16, F64 = 0, 1, 2
-EPI_NONE, EPI_GELU, EPI_TANH, EPI_DGELU, EPI_DTANH = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_TANH, EPI_DGELU, EPI_DTANH, EPI_ADD = 0, 1, 2, 3, 4, 5
 
 _c = ctypes
 _vp, _i, _i64, _f, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -35,7 +35,7 @@ class AttnDesc(ctypes.Structure):
 SIGNATURES = {
     "fcmf_abi_version": [],
     "fcmf_build_info": [],
-    "fcmf_gemm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_gemm_force_tile": [_i],
     "fcmf_colsum": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "fcmf_attn_small_fwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp],
@@ -44,7 +44,8 @@ SIGNATURES = {
     "fcmf_attn_mfma_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _f, _f,
                            _u64, _vp],
     "fcmf_add_ln_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _i, _vp],
-    "fcmf_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _i, _vp],
+    "fcmf_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _i, _vp],
+    "fcmf_add_ln_bwd_workspace": [_i, _i],
     "fcmf_position_ids": [_vp, _vp, _i, _i, _i, _vp],
     "fcmf_embed_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _i, _vp],
     "fcmf_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -84,7 +85,8 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = (ctypes.c_char_p if name == "fcmf_build_info" else
-                          None if name == "fcmf_gemm_force_tile" else ctypes.c_int)
+                          None if name == "fcmf_gemm_force_tile" else
+                          ctypes.c_int64 if name == "fcmf_add_ln_bwd_workspace" else ctypes.c_int)
         _lib = l
     return _lib
 

@@ -24,18 +24,35 @@ def attn_sublayer_params(mod):
 
 def post_attention(layer, ctx, residual, eps, p, training):
     """attention.output.dense -> dropout -> +residual -> LN -> FFN -> dropout -> +res -> LN
-    (BertSelfOutput mm_modeling.py:276-280, BertIntermediate :311-314, BertOutput :324-328)"""
+    (BertSelfOutput mm_modeling.py:276-280, BertIntermediate :311-314, BertOutput :324-328) as ONE
+    autograd node (fused.PostAttentionFn)"""
+    from .fused import PostAttentionFn
     ao = layer.attention.output
-    h = ops.linear(ctx, ao.dense.weight, ao.dense.bias)
-    h1 = ops.add_layer_norm(h, residual, ao.LayerNorm.weight, ao.LayerNorm.bias, eps, p, training)
-    f = ops.ffn(h1, layer.intermediate.dense.weight, layer.intermediate.dense.bias,
-                layer.output.dense.weight, layer.output.dense.bias)
-    return ops.add_layer_norm(f, h1, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, eps, p, training)
+    p = float(p) if training else 0.0
+    s0, s1 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+    return PostAttentionFn.apply(ctx, residual, ao.dense.weight, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias,
+                                 layer.intermediate.dense.weight, layer.intermediate.dense.bias,
+                                 layer.output.dense.weight, layer.output.dense.bias,
+                                 layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, float(eps), p, s0, s1)
 
 
 def transformer_layer(layer, xq, xkv, add_mask, heads, eps, p_hidden, p_attn, training):
-    """Full (unpruned) post-LN layer: xq [B,Tq,H] attends to xkv [B,Tk,H]; add_mask [B,Tk] float32."""
+    """Full (unpruned) post-LN layer: xq [B,Tq,H] attends to xkv [B,Tk,H]; add_mask [B,Tk] float32.
+    Self-attention (xq is xkv) runs as one fused node (fused.SelfLayerFn)."""
     sa = layer.attention.self
+    if xq is xkv and xq.dim() == 3 and xq.shape[1] <= 256 and xq.shape[2] // heads <= 128:
+        from .fused import SelfLayerFn
+        ao = layer.attention.output
+        ph = float(p_hidden) if training else 0.0
+        pa = float(p_attn) if training else 0.0
+        sa_seed = ops.next_seed() if pa > 0 else 0
+        s0, s1 = (ops.next_seed(), ops.next_seed()) if ph > 0 else (0, 0)
+        return SelfLayerFn.apply(xq, add_mask, sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias,
+                                 sa.value.weight, sa.value.bias, ao.dense.weight, ao.dense.bias,
+                                 ao.LayerNorm.weight, ao.LayerNorm.bias, layer.intermediate.dense.weight,
+                                 layer.intermediate.dense.bias, layer.output.dense.weight, layer.output.dense.bias,
+                                 layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, heads, float(eps), ph, pa,
+                                 sa_seed, s0, s1)
     q = ops.linear(xq, sa.query.weight, sa.query.bias)
     k = ops.linear(xkv, sa.key.weight, sa.key.bias)
     v = ops.linear(xkv, sa.value.weight, sa.value.bias)

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import layers, ops
+from .fused import QKVStorageMixin
 from .roberta import RobertaModel
 
 # module constants kept for `from .mm_modeling import *` users (reference mm_modeling.py:21-32)
@@ -60,7 +61,7 @@ class FCMFLayerNorm(nn.Module):
         return ops.add_layer_norm(layers.to_compute(x), None, self.weight, self.bias, self.variance_epsilon)
 
 
-class BertSelfAttention(nn.Module):
+class BertSelfAttention(QKVStorageMixin, nn.Module):
     """reference mm_modeling.py:174-219: returns the merged-head context [B,T,H]"""
 
     def __init__(self, hidden_size=None, num_heads=None):
@@ -73,6 +74,7 @@ class BertSelfAttention(nn.Module):
         self.key = nn.Linear(H, H)
         self.value = nn.Linear(H, H)
         self.dropout = nn.Dropout(ATTENTION_PROBS_DROPOUT_PROB)
+        self._fuse_qkv_storage()
 
     def forward(self, hidden_states, attention_mask):
         return _mha(self, hidden_states, hidden_states, attention_mask)

@@ -164,12 +164,12 @@ def _gemm_kernel_name(A, B, C, bias, aux, M, N, K, lda, ldb, ldc, ta, tb):
     return f"gemm_bf16_kernel<{int(ta)},{int(tb)},{'f32' if C.dtype == torch.float32 else 'bf16'}>"
 
 
-def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI_NONE, acc=False):
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI_NONE, acc=False, colsum=None):
     H.require_cuda(A, B, C)
     if _gemm_trace is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    H.check(H.lib().fcmf_gemm(H.ptr(A), H.ptr(B), H.ptr(C), H.ptr(bias), H.ptr(aux), M, N, K, lda, ldb, ldc,
+    H.check(H.lib().fcmf_gemm(H.ptr(A), H.ptr(B), H.ptr(C), H.ptr(bias), H.ptr(aux), H.ptr(colsum), M, N, K, lda, ldb, ldc,
                               int(ta), int(tb), H.dt(A), H.dt(C), epi, int(acc), H.stream()), "fcmf_gemm")
     if _gemm_trace is not None:
         e1.record()
@@ -277,6 +277,13 @@ def ffn(x, w1, b1, w2, b2):
 # --------------------------------------------------------------------------------------
 # residual + dropout + LayerNorm
 # --------------------------------------------------------------------------------------
+def ln_workspace(rows, Hd, device):
+    """scratch for the per-workgroup partial column sums of fcmf_add_ln_bwd (stream-ordered reuse is safe:
+    every call fully rewrites the part it reads)"""
+    n = H.lib().fcmf_add_ln_bwd_workspace(rows, Hd)
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
 class AddLNFn(torch.autograd.Function):
     """LN(dropout(x) + res): BertSelfOutput / BertOutput / AddNorm (mm_modeling.py:276-280,
     324-328, 570-573) with FCMFLayerNorm (:167-171) or nn.LayerNorm (HF, eps 1e-5)."""
@@ -309,7 +316,7 @@ class AddLNFn(torch.autograd.Function):
         dg = torch.zeros(Hd, dtype=torch.float32, device=z.device)
         db = torch.zeros(Hd, dtype=torch.float32, device=z.device)
         H.check(H.lib().fcmf_add_ln_bwd(H.ptr(dy2), H.ptr(z), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(dz),
-                                        H.ptr(dx), H.ptr(dg), H.ptr(db), rows, Hd, ctx.p, ctx.seed, H.dt(z),
+                                        H.ptr(dx), H.ptr(dg), H.ptr(db), 0, H.ptr(ln_workspace(rows, Hd, z.device)), rows, Hd, ctx.p, ctx.seed, H.dt(z),
                                         H.stream()), "fcmf_add_ln_bwd")
         dxo = (dx if dx is not None else dz).view(ctx.xshape)
         dres = None if ctx.res_shape is None else dz.view(ctx.res_shape)
@@ -393,7 +400,7 @@ class EmbedLNFn(torch.autograd.Function):
         dg = torch.zeros(Hd, dtype=torch.float32, device=z.device)
         db = torch.zeros(Hd, dtype=torch.float32, device=z.device)
         H.check(L.fcmf_add_ln_bwd(H.ptr(d), H.ptr(z), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(dz), 0, H.ptr(dg),
-                                  H.ptr(db), ntok, Hd, 0.0, 0, H.dt(z), H.stream()), "fcmf_add_ln_bwd")
+                                  H.ptr(db), 0, H.ptr(ln_workspace(ntok, Hd, z.device)), ntok, Hd, 0.0, 0, H.dt(z), H.stream()), "fcmf_add_ln_bwd")
         ws, ps, ts = ctx.shapes
         dword = torch.zeros(ws, dtype=torch.float32, device=z.device)
         dpos = torch.zeros(ps, dtype=torch.float32, device=z.device)

@@ -207,10 +207,11 @@ class FusedAdamW(Optimizer):
                                    H.ptr(T['sizes']), H.ptr(T['group']), H.ptr(T['ct']), H.ptr(T['co']), T['nchunks'],
                                    self.CHUNK, lr, wd, ng, b1, b2, eps, step, H.ptr(self._sumsq), mg, st),
                 "fcmf_multi_adamw")
+        ops.shadows.mark_all_stale()          # e.g. fused [3H,H] q|k|v shadows are re-cast lazily
         for (p, _), s in zip(plist, sh):
             self.state[p]['step'] = step
             if s is not None:
-                ops.shadows.mark_fresh(p)
+                ops.shadows.mark_fresh(p)     # refreshed by the kernel itself
         return loss
 
     def grad_norm(self):

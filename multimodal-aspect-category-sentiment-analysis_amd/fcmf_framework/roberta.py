@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import layers, ops
+from .fused import QKVStorageMixin
 
 
 class RobertaConfig:
@@ -63,7 +64,7 @@ class RobertaEmbeddings(nn.Module):
                                     self.dropout.p, self.training, self.padding_idx, ops.compute_dtype())
 
 
-class _SelfAttention(nn.Module):
+class _SelfAttention(QKVStorageMixin, nn.Module):
     def __init__(self, H, heads, p):
         super().__init__()
         self.num_attention_heads = heads
@@ -73,6 +74,7 @@ class _SelfAttention(nn.Module):
         self.key = nn.Linear(H, H)
         self.value = nn.Linear(H, H)
         self.dropout = nn.Dropout(p)
+        self._fuse_qkv_storage()
 
 
 class _SelfOutput(nn.Module):

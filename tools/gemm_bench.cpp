@@ -30,6 +30,16 @@ int main(int argc, char** argv) {
       {"dW   768x3072  TN k=49152", 768, 3072, T, 1, 1, FCMF_EPI_NONE, 1, 1},
       {"fwd  vismap    NT 21952x768x2048", 21952, 768, 2048, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"sq   NT 4096^3", 4096, 4096, 4096, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"probe NOSTORE NT 49152x3072 K=768", T, 3072, 768, 0, 0, 99, 0, 0},
+      {"probe NOSTORE NT 5376x3072 K=768 (252 tiles)", 5376, 3072, 768, 0, 0, 99, 0, 0},
+      {"scan NT 49152x3072 K=256", T, 3072, 256, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"scan NT 49152x3072 K=512", T, 3072, 512, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"scan NT 49152x3072 K=1536", T, 3072, 1536, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"scan NT 49152x3072 K=3072", T, 3072, 3072, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"scan NT 49152x768 K=256", T, 768, 256, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"scan NT 49152x768 K=1536", T, 768, 1536, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"scan NT 5376x3072 K=768 (252 tiles)", 5376, 3072, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"scan NT 5376x3072 K=3072 (252 tiles)", 5376, 3072, 3072, 0, 0, FCMF_EPI_NONE, 0, 0},
   };
   size_t maxA = (size_t)T * 3072, maxB = (size_t)T * 3072, maxC = (size_t)T * 3072;
   unsigned short *A, *B; void *C, *AUX; float* bias;
@@ -49,7 +59,7 @@ int main(int argc, char** argv) {
   for (auto& sh : shapes) {
     int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.N : sh.K, ldc = sh.N;
     auto run = [&]() {
-      return fcmf_gemm(A, B, C, sh.acc ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU) ? AUX : nullptr,
+      return fcmf_gemm(A, B, C, sh.acc ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU) ? AUX : nullptr, nullptr,
                        sh.M, sh.N, sh.K, lda, ldb, ldc, sh.ta, sh.tb, FCMF_BF16, sh.out_f32 ? FCMF_F32 : FCMF_BF16, sh.epi, sh.acc, nullptr);
     };
     int rc = run(); rc |= run();
