@@ -70,6 +70,9 @@ def cpu_baseline(threads_note):
     """the CPU oracle (torch-CPU restatement, `port`) on config C0: B=4, fp32, dropout on, AdamW"""
     import synthetic_data as synth
     from oracle import fcmf_oracle as O
+    # 16 threads = the CPU share of a one-GPU box on this pool and the fastest setting measured on it
+    # (tools/cpu_thread_scan.py: 16 -> 0.53, 32 -> 0.35, 64 -> 0.16, 128 -> 0.04 samples/s fwd+bwd)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     cfg, NI, NR, B = synth.BASE_CFG, 7, 36, 4
     P = {k: v.requires_grad_(True) for k, v in synth.synth_params(synth.fcmf_param_shapes(cfg)).items()}
     groups = O.fcmf_param_groups(list(P))
@@ -101,15 +104,21 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("FCMF_BENCH_SINGLE_DEVICE"):   # rehearsal: several ranks share cuda:0 (use with --backend gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
 
     import synthetic_data as synth
     from fcmf_framework import ops

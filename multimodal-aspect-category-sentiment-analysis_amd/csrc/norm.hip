@@ -172,24 +172,24 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
   }
 }
 
-// out[which][c] += sum_b partial[b][which][c]; one thread per (which, c), blocks strided by 8 row groups
+// out[which][c] += sum_b partial[b][which][c].  grid (H/64, 3, 8): each workgroup sums one eighth of the
+// per-workgroup partial rows for 64 columns (4 waves stride the rows), then one float atomic per column.
 __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partial, int nblocks, int H,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 float* __restrict__ dxsum) {
-  __shared__ float red[8][32];
-  const int col = blockIdx.x * 32 + (threadIdx.x & 31), which = blockIdx.y, part = threadIdx.x >> 5;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane, which = blockIdx.y;
+  float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+  if (!out) return;
+  const int per = (nblocks + gridDim.z - 1) / gridDim.z;
+  const int b0 = blockIdx.z * per, b1 = min(nblocks, b0 + per);
   float s = 0.f;
   if (col < H)
-    for (int b = part; b < nblocks; b += 8) s += partial[((int64_t)b * 3 + which) * H + col];
-  red[part][threadIdx.x & 31] = s;
+    for (int b = b0 + w; b < b1; b += 4) s += partial[((int64_t)b * 3 + which) * H + col];
+  red[w][lane] = s;
   __syncthreads();
-  if (part == 0 && col < H) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
-    float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
-    if (out) out[col] += t;
-  }
+  if (w == 0 && col < H) atomicAdd(out + col, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
 // ---- RoBERTa embeddings -----------------------------------------------------------------
@@ -371,7 +371,7 @@ extern "C" int fcmf_add_ln_bwd(const void* dy, const void* z, const float* gamma
   LN_DISPATCH(dtype, H);
 #undef LAUNCH_
   if (workspace)
-    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((H + 31) / 32, 3), dim3(256), 0, st, workspace, blocks, H, dgamma, dbeta, dxsum);
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((H + 63) / 64, 3, 8), dim3(256), 0, st, workspace, blocks, H, dgamma, dbeta, dxsum);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
