@@ -62,7 +62,8 @@ int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* au
               int trans_a, int trans_b, int in_dtype, int out_dtype,
               int epilogue, int accumulate, void* stream);
 
-/* tuning hook for benchmarks/tests: 0 = built-in heuristic, 128 / 256 = force that block tile */
+/* tuning hook for benchmarks/tests: 0 = built-in heuristic; 128 = 128x128 tiles, 256 = 256x256 (8 waves),
+ * 257 = 256x128 (4 waves, two workgroups per CU) */
 void fcmf_gemm_force_tile(int tile);
 
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X dtype = dtype, out float32. */

@@ -272,19 +272,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // =========================================================================================
-// Large-tile variant for the big GEMMs of the step: 256x256 block tile, BK = 32, 8 waves (2 x 4,
-// 128x64 per wave = 32 accumulator fragments), the same 4-stage LDS-DMA ring (32 KiB per stage,
-// 128 KiB, one workgroup per CU).  Compared with the 128x128 kernel each MFMA needs 25% fewer LDS
-// fragment bytes (12 ds_read_b128 per 32 MFMAs) and half the DMA instructions, and the fragments of
-// k-tile t+1 are read into a second register set while the 32 MFMAs of k-tile t issue.
+// Large-tile kernel family for the big GEMMs of the step.  Every wave owns a 128x64 output tile
+// (32 accumulator fragments of v_mfma_f32_16x16x32_bf16: 12 ds_read_b128 feed 32 MFMAs per k-tile);
+// waves are arranged 2 x WN:
+//   WN = 4: 256x256 block tile, 8 waves, 4-stage LDS-DMA ring (128 KiB, one workgroup per CU),
+//           PING-PONG between the two waves that share a SIMD (see below);
+//   WN = 2: 256x128 block tile, 4 waves, 3-stage ring (72 KiB, TWO workgroups per CU): the second
+//           workgroup's main loop hides this one's prologue / epilogue / barrier skew, which is what
+//           the short-K (K = 768) GEMMs of the layer are bound by.
+// Both are persistent (grid = resident workgroups, each walks the work items tile x k-split), fill the
+// ring with buffer_load_dwordx4 ... lds (swizzle on the source address, range check = zero fill), use a
+// counted vmcnt + ONE raw s_barrier per k-tile, and finish through LDS: accumulators -> f32 staging ->
+// row-wise epilogue (bias, GELU, gelu', tanh', residual add, column sums) with whole-row stores or
+// 256-byte float atomics for split-K.
 // =========================================================================================
-constexpr int GB = 256;                       // block tile edge
-constexpr int BIG_TILE_BYTES = GB * BK * 2;   // 16 KiB per operand tile
-constexpr int BIG_STAGE_BYTES = 2 * BIG_TILE_BYTES;
+constexpr int GB = 256;                       // block tile rows
+constexpr int A_TILE_BYTES = GB * BK * 2;     // 16 KiB
 
 template <bool TR>
-__device__ __forceinline__ unsigned dma_voffset_big(int wave, int j, int lane, int64_t ld, int x0, int xdim) {
-  const int q = (wave * 2 + j) * 64 + lane;   // 16-B slot inside the 16 KiB tile (1024 slots)
+__device__ __forceinline__ unsigned dma_voffset_a(int piece, int lane, int64_t ld, int x0, int xdim) {
+  const int q = piece * 64 + lane;             // 16-B slot inside the 16 KiB A tile (1024 slots)
   if (!TR) {
     const int row = q >> 2, c = (q & 3) ^ swz_row(row);
     if (x0 + row >= xdim) return 0x80000000u;
@@ -296,39 +303,39 @@ __device__ __forceinline__ unsigned dma_voffset_big(int wave, int j, int lane, i
     return (unsigned)(((int64_t)kk * ld + x0 + c16 * 8) * 2);
   }
 }
-
-template <bool TR>
-__device__ __forceinline__ bf16x8 read_frag_big(const char* lds, int x0, int lane) {
+template <bool TR, int BN_>
+__device__ __forceinline__ unsigned dma_voffset_b(int piece, int lane, int64_t ld, int x0, int xdim) {
+  const int q = piece * 64 + lane;             // 16-B slot inside the B tile (BN_ * 4 slots)
   if (!TR) {
-    const int r = x0 + (lane & 15);
-    return *reinterpret_cast<const bf16x8*>(lds + r * 64 + ((((lane >> 4)) ^ swz_row(r)) << 4));
+    const int row = q >> 2, c = (q & 3) ^ swz_row(row);
+    if (x0 + row >= xdim) return 0x80000000u;
+    return (unsigned)(((int64_t)(x0 + row) * ld + c * 8) * 2);
   } else {
-    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-    const int kk = 8 * g + q, f = x0 >> 4;
-    const int off = kk * 512 + ((f ^ tr_key(kk)) << 5) + ((p >> 1) << 4) + ((p & 1) << 3);
-    typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(lds + off));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(lds + off + 4 * 512));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
+    constexpr int CPR = BN_ / 8;               // 16-B chunks per k row
+    const int kk = q / CPR, cp = q % CPR;
+    const int c16 = ((((cp >> 1) ^ tr_key(kk))) << 1) | (cp & 1);
+    if (x0 + c16 * 8 >= xdim) return 0x80000000u;
+    return (unsigned)(((int64_t)kk * ld + x0 + c16 * 8) * 2);
   }
 }
 
-template <bool A_TR, bool B_TR, typename TC>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 x 32 KiB
+template <bool A_TR, bool B_TR, typename TC, int WN, int NST>
+__device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
+  constexpr int NW = 2 * WN;                   // waves
+  constexpr int BN_ = WN * 64;                 // block tile columns
+  constexpr int B_TILE_BYTES = BN_ * BK * 2;
+  constexpr int STAGE_BYTES_ = A_TILE_BYTES + B_TILE_BYTES;
+  constexpr int A_PIECES = 16 / NW, B_PIECES = (B_TILE_BYTES / 1024) / NW, PIECES = A_PIECES + B_PIECES;
+  constexpr int B_ROW = BN_ * 2;               // bytes per k row of a transposed B tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;      // 2 x 4 waves: rows wm*128, cols wn*64
+  const int wm = wave / WN, wn = wave % WN;    // rows wm*128, cols wn*64
 
-  // PERSISTENT workgroups: the grid is at most one workgroup per CU and each walks the work items
-  // (output tile x k-split) round by round.  Workgroups drift out of lockstep after the first round,
-  // so the HBM write bursts of the epilogues overlap other CUs' main loops instead of colliding.
-  // XCD-aware order inside a round: the workgroups of one XCD (blockIdx % 8) take consecutive
-  // logical items, and consecutive items share the A row-panel (all N tiles of one M tile) -> L2 hits.
-  const int tiles_n = (p.N + GB - 1) / GB;
+  // PERSISTENT workgroups: each walks the work items (output tile x k-split) round by round.
+  // XCD-aware order inside a round: the workgroups of one XCD (blockIdx % 8) take consecutive logical
+  // items, and consecutive items share the A row-panel (all N tiles of one M tile) -> L2 hits.
+  const int tiles_n = (p.N + BN_ - 1) / BN_;
   const int nblk = gridDim.x;
   int slot = blockIdx.x;
   {
@@ -336,53 +343,20 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
     slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
   const int nk_total = (p.K + BK - 1) / BK;
-  for (int item = slot; item < p.total_items; item += nblk) {
-  const int zsplit = item / p.tiles, tile = item - zsplit * p.tiles;
-  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
-  const int i0 = tile_m * GB, j0 = tile_n * GB;
-  const int kt_begin = zsplit * p.ktiles_per_split;
-  const int kt_end = min(nk_total, kt_begin + p.ktiles_per_split);
-  const int nkt = kt_end - kt_begin;
-
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
-  unsigned va[2], vb[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    va[j] = dma_voffset_big<A_TR>(wave, j, lane, p.lda, i0, p.M);
-    vb[j] = dma_voffset_big<B_TR>(wave, j, lane, p.ldb, j0, p.N);
-  }
   const unsigned a_step = A_TR ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
   const unsigned b_step = B_TR ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
-
-  auto issue = [&](int t) {
-    char* st = smem + (t & (NSTAGE - 1)) * BIG_STAGE_BYTES + (wave * 2) * 1024;
-    const unsigned ka = (unsigned)(kt_begin + t) * a_step, kb = (unsigned)(kt_begin + t) * b_step;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j] + ka, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j], ka, 0, 0);
-      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + BIG_TILE_BYTES + j * 1024), 16, vb[j] + kb, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + BIG_TILE_BYTES + j * 1024), 16, vb[j], kb, 0, 0);
-    }
-  };
-  // Fragment pipeline (registers: B double-buffered, A in two halves):
-  //   phase 1 of tile t: read A_hi(t)                      | 16 MFMAs  A_lo(t) x B(t)
-  //   phase 2 of tile t: wait + barrier for tile t+1, DMA tile t+3,
-  //                      read A_lo(t+1)                    | 16 MFMAs  A_hi(t) x B(t)
-  //                      then read B(t+1)
-  // Per-lane LDS offsets are computed ONCE; fragment f of a K-contiguous operand is then a constant
-  // 1 KiB step away (row bit 3, which drives the swizzle, does not depend on f), so the reads of
-  // one operand share a base VGPR + immediate offsets.
+  // Per-lane LDS offsets are computed ONCE; fragment f of a K-contiguous operand is a constant 1 KiB
+  // step away (row bit 3, which drives the swizzle, does not depend on f).
   typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
   const int rowl = lane & 15, g4 = lane >> 4, q4 = rowl >> 2, p4 = rowl & 3;
-  const int row_base = rowl * 64 + ((g4 ^ swz_row(rowl)) << 4);                       // K-contiguous image
-  const int tr_base = (8 * g4 + q4) * 512 + ((p4 >> 1) << 4) + ((p4 & 1) << 3);       // transposed image
+  const int row_base = rowl * 64 + ((g4 ^ swz_row(rowl)) << 4);
   const int trk = tr_key(8 * g4 + q4);
-  const int a_lane = A_TR ? tr_base : row_base + wm * 128 * 64;
-  const int b_lane = BIG_TILE_BYTES + (B_TR ? tr_base : row_base + wn * 64 * 64);
-  auto stage_ptr = [&](int t) { return smem + (t & (NSTAGE - 1)) * BIG_STAGE_BYTES; };
-  auto frag_a = [&](const char* st, int f) -> bf16x8 {     // f = 0..7 (16-row fragment of this wave's 128 rows)
+  const int tr_col = ((p4 >> 1) << 4) + ((p4 & 1) << 3);
+  const int a_lane = A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * 128 * 64;
+  const int b_lane = A_TILE_BYTES + (B_TR ? (8 * g4 + q4) * B_ROW + tr_col : row_base + wn * 64 * 64);
+  auto frag_a = [&](const char* st, int f) -> bf16x8 {     // f = 0..7: 16-row fragment of this wave's 128 rows
     if (!A_TR) return *reinterpret_cast<const bf16x8*>(st + a_lane + f * 1024);
     const char* q = st + a_lane + (((wm * 8 + f) ^ trk) << 5);
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
@@ -395,20 +369,55 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
     if (!B_TR) return *reinterpret_cast<const bf16x8*>(st + b_lane + f * 1024);
     const char* q = st + b_lane + (((wn * 4 + f) ^ trk) << 5);
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * 512));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * B_ROW));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
   };
-  auto load_a = [&](int t, int half, bf16x8 (&fa)[4]) {
-    const char* st = stage_ptr(t);
+
+  for (int item = slot; item < p.total_items; item += nblk) {
+  const int zsplit = item / p.tiles, tile = item - zsplit * p.tiles;
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  const int i0 = tile_m * GB, j0 = tile_n * BN_;
+  const int kt_begin = zsplit * p.ktiles_per_split;
+  const int kt_end = min(nk_total, kt_begin + p.ktiles_per_split);
+  const int nkt = kt_end - kt_begin;
+
+  unsigned va[A_PIECES], vb[B_PIECES];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) fa[f] = frag_a(st, half * 4 + f);
+  for (int j = 0; j < A_PIECES; ++j) va[j] = dma_voffset_a<A_TR>(wave * A_PIECES + j, lane, p.lda, i0, p.M);
+#pragma unroll
+  for (int j = 0; j < B_PIECES; ++j) vb[j] = dma_voffset_b<B_TR, BN_>(wave * B_PIECES + j, lane, p.ldb, j0, p.N);
+
+  auto stage_ptr = [&](int t) { return smem + (t % NST) * STAGE_BYTES_; };
+  auto issue = [&](int t) {
+    char* st = stage_ptr(t);
+    const unsigned ka = (unsigned)(kt_begin + t) * a_step, kb = (unsigned)(kt_begin + t) * b_step;
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) {
+      char* d = st + (wave * A_PIECES + j) * 1024;
+      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va[j] + ka, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va[j], ka, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PIECES; ++j) {
+      char* d = st + A_TILE_BYTES + (wave * B_PIECES + j) * 1024;
+      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb[j] + kb, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb[j], kb, 0, 0);
+    }
   };
-  auto load_b = [&](int t, bf16x8 (&fb)[4]) {
-    const char* st = stage_ptr(t);
-#pragma unroll
-    for (int f = 0; f < 4; ++f) fb[f] = frag_b(st, f);
+  // own DMAs of tile t have landed once at most `younger` later tiles (PIECES DMAs each) are outstanding
+  auto wait_landed = [&](int t) {
+    int younger = nkt - 1 - t;
+    if (younger > NST - 2) younger = NST - 2;
+    if (PIECES == 4) {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   };
 
   f32x4 acc[4][8];  // [j frag][i frag]
@@ -416,61 +425,63 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // the accumulator index must be a compile-time constant (runtime-indexed arrays go to scratch)
-  auto mma_lo = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+  bf16x8 fa[8], fb[4];
+  auto load_frags = [&](int t) {
+    const char* st = stage_ptr(t);
 #pragma unroll
-    for (int fi = 0; fi < 4; ++fi)
+    for (int f = 0; f < 4; ++f) fb[f] = frag_b(st, f);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) fa[f] = frag_a(st, f);
+  };
+  auto mma = [&]() {
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj)
+        // D rows <- B operand (j), D cols <- A operand (i)
         acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[fj], fa[fi], acc[fj][fi], 0, 0, 0);
   };
-  auto mma_hi = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
-#pragma unroll
-    for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-      for (int fj = 0; fj < 4; ++fj)
-        acc[fj][4 + fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[fj], fa[fi], acc[fj][4 + fi], 0, 0, 0);
-  };
-  // wait until k-tile `t` has landed: at most one younger tile (4 DMAs) may stay in flight
-  auto wait_tile = [&](int t) {
-    if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
 
-  // One register set per fragment group (acc 128 + 3 x 16 VGPRs): no unrolled double buffering, so
-  // the accumulators stay in place around the loop.
-  bf16x8 alo[4], ahi[4], bb[4];
-  if (nkt > 0) {
-    issue(0);
-    if (nkt > 1) issue(1);
-    wait_tile(0);
-    __builtin_amdgcn_s_barrier();
-    if (nkt > 2) issue(2);
-    load_b(0, bb);
-    load_a(0, 0, alo);
-  }
-  for (int t = 0; t < nkt; ++t) {
-    load_a(t, 1, ahi);                 // streams in under the first 16 MFMAs
-    mma_lo(alo, bb);
-    if (t + 1 < nkt) {
-      wait_tile(t + 1);
-      __builtin_amdgcn_s_barrier();    // tile t+1 visible to all waves; stage (t+3)&3 free
-      if (t + 3 < nkt) issue(t + 3);
-      load_a(t + 1, 0, alo);           // streams in under the second 16 MFMAs
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nkt) issue(t);
+  // PING-PONG (8-wave variant): waves w and w+4 share a SIMD.  Between barrier t and barrier t+1
+  // group A (waves 0-3) feeds (DMA tile t+3, fragment reads of tile t) THEN multiplies tile t, while
+  // group B (waves 4-7) multiplies tile t-1 FIRST (fragments read in the previous interval) and feeds
+  // tile t afterwards: the SIMD's matrix pipe sees A's 32 MFMAs while B feeds and vice versa.
+  const bool group_b = (WN == 4) && wave >= 4;     // wave is an SGPR: a uniform branch
+  if (!group_b) {
+    for (int t = 0; t < nkt; ++t) {
+      wait_landed(t);
+      __builtin_amdgcn_s_barrier();            // tile t visible; the stage of tile t-1 is no longer read
+      if (t + NST - 1 < nkt) issue(t + NST - 1);
+      load_frags(t);
+      mma();
     }
-    mma_hi(ahi, bb);
-    if (t + 1 < nkt) load_b(t + 1, bb);
+  } else {
+    for (int t = 0; t < nkt; ++t) {
+      wait_landed(t);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads of tile t-1 have left LDS
+      __builtin_amdgcn_s_barrier();
+      if (t > 0) mma();                                     // tile t-1
+      if (t + NST - 1 < nkt) issue(t + NST - 1);
+      load_frags(t);
+    }
+    if (nkt > 0) mma();                                     // last tile
   }
 
   // ---- epilogue: accumulators -> LDS (f32, one 128-row half at a time) -> row-wise output -----
   // Fragment-layout stores touch 16 rows x 32 B per instruction and are store-issue bound; going
-  // through LDS every wave instruction writes (or atomically adds) whole 512-B / 256-B row pieces,
-  // and bias / GELU / gelu' / tanh' run on contiguous 8-element groups with coalesced aux accesses.
+  // through LDS every wave instruction writes (or atomically adds) whole row pieces, and bias / GELU /
+  // gelu' / tanh' / residual add run on contiguous 8-element groups with coalesced aux accesses.
+  constexpr int LPR = BN_ / 8;                 // lanes per output row (8 columns each)
+  constexpr int RPI = 64 / LPR;                // rows per wave instruction
+  constexpr int RPW = 128 / NW;                // rows per wave per half
   TC* C = reinterpret_cast<TC*>(p.C);
   TC* AUX = reinterpret_cast<TC*>(p.aux);
   const bool atomic = (p.ksplit > 1);
   const bool lead = (zsplit == 0);
-  float* Ct = reinterpret_cast<float*>(smem);   // [128][256] f32; 16-B chunk index XOR (row & 7)
+  float* Ct = reinterpret_cast<float*>(smem);   // [128][BN_] f32; 16-B chunk index XOR (row & 7)
   __syncthreads();                              // every wave is done with the operand ring
   float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
@@ -482,7 +493,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) {
           const int chunk = wn * 16 + fj * 4 + (lane >> 4);
-          *reinterpret_cast<f32x4*>(Ct + row * 256 + ((chunk ^ (row & 7)) << 2)) = acc[fj][fi];
+          *reinterpret_cast<f32x4*>(Ct + row * BN_ + ((chunk ^ (row & 7)) << 2)) = acc[fj][fi];
         }
       }
     }
@@ -490,29 +501,28 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
     if (atomic) {
       // split-K partial: 256-B contiguous float atomics (one dword per lane, full-rate shape)
       float* Cf = reinterpret_cast<float*>(C);
-      for (int it = 0; it < 16; ++it) {
-        const int row = wave * 16 + it, gi = i0 + half * 128 + row;
+      for (int it = 0; it < RPW; ++it) {
+        const int row = wave * RPW + it, gi = i0 + half * 128 + row;
         if (gi >= p.M) continue;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < BN_ / 64; ++k) {
           const int col = lane + 64 * k, gj = j0 + col;
-          if (gj < p.N) atomicAdd(Cf + (int64_t)gi * p.ldc + gj, Ct[row * 256 + ((((col >> 2)) ^ (row & 7)) << 2) + (col & 3)]);
+          if (gj < p.N) atomicAdd(Cf + (int64_t)gi * p.ldc + gj, Ct[row * BN_ + ((((col >> 2)) ^ (row & 7)) << 2) + (col & 3)]);
         }
       }
     } else {
-      for (int it = 0; it < 8; ++it) {
-        const int row = wave * 16 + it * 2 + (lane >> 5), gi = i0 + half * 128 + row;
-        const int c0 = (lane & 31) * 2, gj = j0 + c0 * 4;
+      for (int it = 0; it < RPW / RPI; ++it) {
+        const int row = wave * RPW + it * RPI + lane / LPR, gi = i0 + half * 128 + row;
+        const int c0 = (lane % LPR) * 2, gj = j0 + c0 * 4;
         if (gi >= p.M || gj >= p.N) continue;
         float v[8];
-        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(Ct + row * 256 + ((c0 ^ (row & 7)) << 2));
-        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(Ct + row * 256 + (((c0 + 1) ^ (row & 7)) << 2));
+        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(Ct + row * BN_ + ((c0 ^ (row & 7)) << 2));
+        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(Ct + row * BN_ + (((c0 + 1) ^ (row & 7)) << 2));
         if (p.bias && lead) {
           const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gj), b1 = *reinterpret_cast<const float4*>(p.bias + gj + 4);
           v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
         const int64_t off = (int64_t)gi * p.ldc + gj;
-        if (p.epilogue == 99) { if (v[0] == 123.456f) C[off] = from_f32<TC>(v[1]); continue; }   // timing probe: no stores
         if (p.epilogue != FCMF_EPI_NONE) {
           float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
           if (p.epilogue == FCMF_EPI_GELU) {
@@ -548,20 +558,21 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmParams p) {
     __syncthreads();
   }
   if (p.colsum) {
-    // a lane owns 8 fixed columns over 16 rows of the block tile; lanes l and l^32 share columns.
-    // Reduce the 8 waves through LDS first: ONE float atomic per column per workgroup (all row
-    // tiles of a column add to the same 256 addresses, so fewer, larger adds matter).
-    float* red = reinterpret_cast<float*>(smem);    // [8 waves][256]
+    // a lane owns 8 fixed columns; lanes that differ only above the LPR bits share them.  Reduce the
+    // waves through LDS first: ONE float atomic per column per workgroup.
+    float* red = reinterpret_cast<float*>(smem);    // [NW][BN_]
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float t = csum[e] + __shfl_xor(csum[e], 32, 64);
-      if (lane < 32) red[wave * 256 + lane * 8 + e] = t;
+      float t = csum[e];
+      if (LPR <= 16) t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (lane < LPR) red[wave * BN_ + lane * 8 + e] = t;
     }
     __syncthreads();
-    if (tid < 256) {
+    if (tid < BN_) {
       float t = 0.f;
 #pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) t += red[w8 * 256 + tid];
+      for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * BN_ + tid];
       if (j0 + tid < p.N) atomicAdd(p.colsum + j0 + tid, t);
     }
   }
@@ -713,22 +724,37 @@ static int launch_bf16(const GemmParams& p, int out_dtype, dim3 grid, hipStream_
   return FCMF_OK;
 }
 
-template <bool A_TR, bool B_TR>
-static int launch_bf16_big(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st) {
-  size_t smem = NSTAGE * BIG_STAGE_BYTES;
-  if (out_dtype == FCMF_F32) {
-    auto k = gemm_bf16_big_kernel<A_TR, B_TR, float>;
+// literal launch bounds per shape (template-dependent bounds are not instantiable on the host)
+template <bool A_TR, bool B_TR, typename TC>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmParams p) {
+  gemm_bf16_tile_body<A_TR, B_TR, TC, 4, 4>(p);
+}
+template <bool A_TR, bool B_TR, typename TC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tile128n_kernel(GemmParams p) {
+  gemm_bf16_tile_body<A_TR, B_TR, TC, 2, 3>(p);
+}
+
+template <bool A_TR, bool B_TR, typename TC, int WN>
+static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
+  if constexpr (WN == 4) {
+    auto k = gemm_bf16_tile256_kernel<A_TR, B_TR, TC>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
   } else {
-    auto k = gemm_bf16_big_kernel<A_TR, B_TR, bf16_t>;
+    auto k = gemm_bf16_tile128n_kernel<A_TR, B_TR, TC>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, p);
   }
+}
+
+template <bool A_TR, bool B_TR, int WN, int NST>
+static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st) {
+  const size_t smem = (size_t)NST * (A_TILE_BYTES + WN * 64 * BK * 2);
+  if (out_dtype == FCMF_F32) launch_bf16_tile_typed<A_TR, B_TR, float, WN>(p, grid, smem, st);
+  else launch_bf16_tile_typed<A_TR, B_TR, bf16_t, WN>(p, grid, smem, st);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
-
 static int g_num_cus = 256;    // MI355X: 8 XCDs x 32 CUs; one persistent 128-KiB-LDS workgroup per CU
 static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced (benchmarks, tests)
 extern "C" void fcmf_gemm_force_tile(int tile) { g_force_tile = tile; }
@@ -760,28 +786,39 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     p.a_bytes = (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
     p.b_bytes = (unsigned)((((int64_t)(trans_b ? K : N) - 1) * ldb + (trans_b ? N : K)) * 2);
     const int nk = (K + BK - 1) / BK;
-    const int tiles_big = ((M + GB - 1) / GB) * ((N + GB - 1) / GB);
-    // 256x256 tiles once there is enough work to fill the chip with them (directly or through split-K)
-    bool big = M >= 256 && N >= 256 && ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && (int64_t)M * N * K >= (1ll << 33))) &&
-               (N % 8 == 0) && (ldc % 8 == 0);
-    if (g_force_tile == 128) big = false;
-    if (g_force_tile == 256) big = (N % 8 == 0) && (ldc % 8 == 0);
-    if (big) {
+    // tile family: 256x256 (8 waves, 1 workgroup/CU) wherever N allows it; 256x128 (4 waves, 2 workgroups/CU,
+    // one hides the other's prologue/epilogue) only for very short K or narrow N -- measured on MI355X the
+    // 256x256 ping-pong kernel wins from K = 512 up; 128x128 for small / ragged outputs
+    bool large = M >= 256 && N >= 128 && ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && (int64_t)M * N * K >= (1ll << 33))) &&
+                 (N % 8 == 0) && (ldc % 8 == 0);
+    int wn = (N >= 256 && nk >= 12) ? 4 : 2;
+    if (g_force_tile == 128) large = false;
+    if (g_force_tile == 256 || g_force_tile == 257) { large = (N % 8 == 0) && (ldc % 8 == 0); wn = g_force_tile == 256 ? 4 : 2; }
+    if (large) {
+      const int bn = wn * 64, slots = wn == 4 ? g_num_cus : 2 * g_num_cus;
+      const int tiles_l = ((M + GB - 1) / GB) * ((N + bn - 1) / bn);
       int ksplit = 1;
-      if (accumulate && epilogue == FCMF_EPI_NONE && tiles_big < 256) {
-        ksplit = 256 / tiles_big;
+      if (accumulate && epilogue == FCMF_EPI_NONE && tiles_l < slots) {
+        ksplit = slots / tiles_l;
         if (ksplit > nk / 8) ksplit = nk / 8 > 0 ? nk / 8 : 1;
         if (ksplit > 64) ksplit = 64;
       }
       p.ktiles_per_split = (nk + ksplit - 1) / ksplit;
       p.ksplit = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
-      p.tiles = tiles_big;
-      p.total_items = tiles_big * p.ksplit;
-      dim3 grid(p.total_items < g_num_cus ? p.total_items : g_num_cus);
-      if (!trans_a && !trans_b) return launch_bf16_big<false, false>(p, out_dtype, grid, st);
-      if (!trans_a && trans_b) return launch_bf16_big<false, true>(p, out_dtype, grid, st);
-      if (trans_a && !trans_b) return launch_bf16_big<true, false>(p, out_dtype, grid, st);
-      return launch_bf16_big<true, true>(p, out_dtype, grid, st);
+      p.tiles = tiles_l;
+      p.total_items = tiles_l * p.ksplit;
+      dim3 grid(p.total_items < slots ? p.total_items : slots);
+      const int v = (wn == 4 ? 0 : 4) + (trans_a ? 2 : 0) + (trans_b ? 1 : 0);
+      switch (v) {
+        case 0: return launch_bf16_tile<false, false, 4, 4>(p, out_dtype, grid, st);
+        case 1: return launch_bf16_tile<false, true, 4, 4>(p, out_dtype, grid, st);
+        case 2: return launch_bf16_tile<true, false, 4, 4>(p, out_dtype, grid, st);
+        case 3: return launch_bf16_tile<true, true, 4, 4>(p, out_dtype, grid, st);
+        case 4: return launch_bf16_tile<false, false, 2, 3>(p, out_dtype, grid, st);
+        case 5: return launch_bf16_tile<false, true, 2, 3>(p, out_dtype, grid, st);
+        case 6: return launch_bf16_tile<true, false, 2, 3>(p, out_dtype, grid, st);
+        default: return launch_bf16_tile<true, true, 2, 3>(p, out_dtype, grid, st);
+      }
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int ksplit = 1;

@@ -43,11 +43,11 @@ def test_gemm_layouts(dev, dtype, ta, tb, M, N, K):
     assert rel_err(C, ref) < TOL[dtype], (ta, tb, M, N, K)
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 257])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(700, 520, 96), (256, 256, 32), (1000, 776, 224)])
 def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
-    """both MFMA kernels (128x128 and 256x256 block tiles) on ragged M/N edges and odd k-tile counts"""
+    """all MFMA tile kernels (128x128, 256x256 ping-pong, 256x128) on ragged M/N edges and odd k-tile counts"""
     ops, H = _ops()
     A = _rand((K, M) if ta else (M, K), dev, torch.bfloat16, seed=1)
     B = _rand((K, N) if tb else (N, K), dev, torch.bfloat16, seed=2)
