@@ -13,31 +13,52 @@ struct GemmParams {
   int64_t lda, ldb, ldc;
   int epilogue, accumulate, ksplit, ktiles_per_split;
   unsigned a_bytes, b_bytes;   // extents of A / B for the buffer range check
+  unsigned c_bytes;            // extent of C (and aux) in bytes, tile kernels with 2-byte outputs
   float* colsum;               // optional: colsum[n] += sum_m C[m,n] (bias gradient of the producing layer)
   int tiles, total_items;      // persistent big kernel: output tiles, tiles x k-splits
 };
 
-// bf16-output epilogues use odd minimax-style polynomials instead of erf/exp (no transcendental
-// issue slots): Phi(x) - 0.5 ~= x * P7(x^2) on |x| <= 4 (|err| <= 8e-5) and gelu'(x) - 0.5 ~= x * Q9(x^2)
-// on |x| <= 4.5 (|err| <= 3e-4), both far below bf16 resolution; saturated outside (tools: the fits
-// are reproduced by the snippet in DESIGN.md).  The f32 parity path keeps the exact erff forms.
-__device__ __forceinline__ float gelu_poly(float x) {
-  const float ax = fminf(fabsf(x), 4.0f), t = ax * ax;
-  float p = -1.992937524e-09f;
-  p = p * t + 1.462821838e-07f; p = p * t - 4.685912798e-06f; p = p * t + 8.774612016e-05f;
-  p = p * t - 1.093923500e-03f; p = p * t + 9.815655956e-03f; p = p * t - 6.639252684e-02f;
-  p = p * t + 3.989359758e-01f;
-  const float phi = 0.5f + copysignf(ax * p, x);
-  return x >= 4.0f ? x : (x <= -4.0f ? 0.0f : x * phi);
+// bf16-output epilogues use odd polynomials instead of erf/exp (no transcendental issue slots, no
+// selects): with xc = clamp(x, -X, X),
+//   Phi(x)   ~= 0.5 + xc * P7(xc^2), X = 4.0  (|err| <= 3.4e-5; gelu = x * Phi: |err| <= 1.4e-4)
+//   gelu'(x) ~= 0.5 + xc * Q9(xc^2), X = 4.5  (|err| <= 2e-4)
+// both constrained to hit exactly 1 (0) at +X (-X), so the clamp alone saturates them; all far below
+// bf16 resolution.  Evaluated two elements at a time on the packed-f32 pipe (v_pk_fma_f32).  The fits are
+// reproduced by the snippet in DESIGN.md.  The f32 parity path keeps the exact erff forms.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
+__device__ __forceinline__ f32x2 clamp2(f32x2 x, float lim) {
+  return f32x2{__builtin_amdgcn_fmed3f(x[0], -lim, lim), __builtin_amdgcn_fmed3f(x[1], -lim, lim)};
 }
-__device__ __forceinline__ float dgelu_poly(float x) {
-  const float ax = fminf(fabsf(x), 4.5f), t = ax * ax;
-  float p = -2.897521759e-11f;
-  p = p * t + 3.178414279e-09f; p = p * t - 1.532542835e-07f; p = p * t + 4.303428593e-06f;
-  p = p * t - 7.880709165e-05f; p = p * t + 1.000204828e-03f; p = p * t - 9.090597788e-03f;
-  p = p * t + 5.929092316e-02f; p = p * t - 2.656870675e-01f; p = p * t + 7.978704071e-01f;
-  return 0.5f + copysignf(ax * p, x);
+// (written on 4-wide vectors: the compiler splits every step into two independent v_pk_fma_f32, so the
+// two Horner chains interleave and hide the packed-math dependency stall)
+__device__ __forceinline__ f32x4 clamp4(f32x4 x, float lim) {
+  return f32x4{__builtin_amdgcn_fmed3f(x[0], -lim, lim), __builtin_amdgcn_fmed3f(x[1], -lim, lim),
+               __builtin_amdgcn_fmed3f(x[2], -lim, lim), __builtin_amdgcn_fmed3f(x[3], -lim, lim)};
 }
+__device__ __forceinline__ f32x4 splat4(float c) { return f32x4{c, c, c, c}; }
+__device__ __forceinline__ f32x4 phi_poly4(f32x4 x) {      // Phi(x)
+  const f32x4 xc = clamp4(x, 4.0f), t = xc * xc;
+  f32x4 p = splat4(-1.304578543e-09f);
+  p = p * t + splat4(1.060087872e-07f); p = p * t + splat4(-3.746289010e-06f); p = p * t + splat4(7.662426288e-05f);
+  p = p * t + splat4(-1.023770734e-03f); p = p * t + splat4(9.590060957e-03f); p = p * t + splat4(-6.607606400e-02f);
+  p = p * t + splat4(3.988102128e-01f);
+  return xc * p + splat4(0.5f);
+}
+__device__ __forceinline__ f32x4 dgelu_poly4(f32x4 x) {    // gelu'(x)
+  const f32x4 xc = clamp4(x, 4.5f), t = xc * xc;
+  f32x4 p = splat4(-2.396099311e-11f);
+  p = p * t + splat4(2.702686828e-09f); p = p * t + splat4(-1.343048027e-07f); p = p * t + splat4(3.892256086e-06f);
+  p = p * t + splat4(-7.353425424e-05f); p = p * t + splat4(9.596712397e-04f); p = p * t + splat4(-8.909952021e-03f);
+  p = p * t + splat4(5.886488750e-02f); p = p * t + splat4(-2.652524630e-01f); p = p * t + splat4(7.977590902e-01f);
+  return xc * p + splat4(0.5f);
+}
+__device__ __forceinline__ f32x2 phi_poly2(f32x2 x) { const f32x4 r = phi_poly4(f32x4{x[0], x[1], x[0], x[1]}); return f32x2{r[0], r[1]}; }
+__device__ __forceinline__ f32x2 dgelu_poly2(f32x2 x) { const f32x4 r = dgelu_poly4(f32x4{x[0], x[1], x[0], x[1]}); return f32x2{r[0], r[1]}; }
+__device__ __forceinline__ float gelu_poly(float x) { const f32x2 v{x, x}; return (v * phi_poly2(v))[0]; }
+__device__ __forceinline__ float dgelu_poly(float x) { return dgelu_poly2(f32x2{x, x})[0]; }
 __device__ __forceinline__ float apply_epilogue_fast(float v, int epi, float auxv) {
   switch (epi) {
     case FCMF_EPI_GELU: return gelu_poly(v);
@@ -319,7 +340,31 @@ __device__ __forceinline__ unsigned dma_voffset_b(int piece, int lane, int64_t l
   }
 }
 
-template <bool A_TR, bool B_TR, typename TC, int WN, int NST>
+template <int E> struct EpiTag { static constexpr int value = E; };
+// 8 consecutive outputs of one row <-> four packed-f32 pairs
+template <typename TC> __device__ __forceinline__ void load8(const TC* q, f32x2 (&v)[4]);
+template <> __device__ __forceinline__ void load8<float>(const float* q, f32x2 (&v)[4]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(q), b = *reinterpret_cast<const f32x4*>(q + 4);
+  v[0] = f32x2{a[0], a[1]}; v[1] = f32x2{a[2], a[3]}; v[2] = f32x2{b[0], b[1]}; v[3] = f32x2{b[2], b[3]};
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* q, f32x2 (&v)[4]) {
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(q);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = f32x2{(float)a[2 * e], (float)a[2 * e + 1]};
+}
+template <typename TC> __device__ __forceinline__ void store8(TC* q, const f32x2 (&v)[4]);
+template <> __device__ __forceinline__ void store8<float>(float* q, const f32x2 (&v)[4]) {
+  *reinterpret_cast<f32x4*>(q) = f32x4{v[0][0], v[0][1], v[1][0], v[1][1]};
+  *reinterpret_cast<f32x4*>(q + 4) = f32x4{v[2][0], v[2][1], v[3][0], v[3][1]};
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* q, const f32x2 (&v)[4]) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[2 * e] = (bf16_t)v[e][0]; o[2 * e + 1] = (bf16_t)v[e][1]; }
+  *reinterpret_cast<bf16x8*>(q) = o;
+}
+
+template <bool A_TR, bool B_TR, typename TC, int EPI, int WN, int NST>
 __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
   constexpr int NW = 2 * WN;                   // waves
   constexpr int BN_ = WN * 64;                 // block tile columns
@@ -375,38 +420,48 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
     return r;
   };
 
-  for (int item = slot; item < p.total_items; item += nblk) {
-  const int zsplit = item / p.tiles, tile = item - zsplit * p.tiles;
-  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
-  const int i0 = tile_m * GB, j0 = tile_n * BN_;
-  const int kt_begin = zsplit * p.ktiles_per_split;
-  const int kt_end = min(nk_total, kt_begin + p.ktiles_per_split);
-  const int nkt = kt_end - kt_begin;
-
-  unsigned va[A_PIECES], vb[B_PIECES];
-#pragma unroll
-  for (int j = 0; j < A_PIECES; ++j) va[j] = dma_voffset_a<A_TR>(wave * A_PIECES + j, lane, p.lda, i0, p.M);
-#pragma unroll
-  for (int j = 0; j < B_PIECES; ++j) vb[j] = dma_voffset_b<B_TR, BN_>(wave * B_PIECES + j, lane, p.ldb, j0, p.N);
-
+  struct Item { int i0, j0, kt_begin, nkt, zsplit; };
+  auto decode = [&](int item) -> Item {
+    const int zsplit = item / p.tiles, tile = item - zsplit * p.tiles;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int kb = zsplit * p.ktiles_per_split;
+    return Item{tile_m * GB, tile_n * BN_, kb, min(nk_total, kb + p.ktiles_per_split) - kb, zsplit};
+  };
   auto stage_ptr = [&](int t) { return smem + (t % NST) * STAGE_BYTES_; };
-  auto issue = [&](int t) {
+  // DMA of k-tile t (relative to the item's first) into ring stage t % NST; (i0, j0) -> per-lane source offsets
+  auto issue = [&](const Item& w, int t) {
     char* st = stage_ptr(t);
-    const unsigned ka = (unsigned)(kt_begin + t) * a_step, kb = (unsigned)(kt_begin + t) * b_step;
+    const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
       char* d = st + (wave * A_PIECES + j) * 1024;
-      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va[j] + ka, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va[j], ka, 0, 0);
+      const unsigned va = dma_voffset_a<A_TR>(wave * A_PIECES + j, lane, p.lda, w.i0, p.M);
+      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va + ka, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va, ka, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j) {
       char* d = st + A_TILE_BYTES + (wave * B_PIECES + j) * 1024;
-      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb[j] + kb, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb[j], kb, 0, 0);
+      const unsigned vb = dma_voffset_b<B_TR, BN_>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
+      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb + kb, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb, kb, 0, 0);
     }
   };
+  auto lds_barrier = [&]() {   // LDS traffic of this wave retired, then the workgroup barrier; global stores stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // bf16 outputs stage through HALF the ring, so the first NPRE k-tiles of the NEXT work item are put in
+  // flight before the epilogue starts (their DMA latency hides under it)
+  constexpr bool PREFETCH = (WN == 4) && sizeof(TC) == 2;
+  constexpr int NPRE = 2;
+  bool pre = false;
+
+  for (int item = slot; item < p.total_items; item += nblk) {
+  const Item w = decode(item);
+  const int i0 = w.i0, j0 = w.j0, nkt = w.nkt;
   // own DMAs of tile t have landed once at most `younger` later tiles (PIECES DMAs each) are outstanding
+  // (loads retire in order; stores of the previous epilogue that are still in flight only make the wait longer)
   auto wait_landed = [&](int t) {
     int younger = nkt - 1 - t;
     if (younger > NST - 2) younger = NST - 2;
@@ -444,7 +499,7 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
 
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
-    if (t < nkt) issue(t);
+    if (t < nkt && !(pre && t < NPRE)) issue(w, t);
   // PING-PONG (8-wave variant): waves w and w+4 share a SIMD.  Between barrier t and barrier t+1
   // group A (waves 0-3) feeds (DMA tile t+3, fragment reads of tile t) THEN multiplies tile t, while
   // group B (waves 4-7) multiplies tile t-1 FIRST (fragments read in the previous interval) and feeds
@@ -454,7 +509,7 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
     for (int t = 0; t < nkt; ++t) {
       wait_landed(t);
       __builtin_amdgcn_s_barrier();            // tile t visible; the stage of tile t-1 is no longer read
-      if (t + NST - 1 < nkt) issue(t + NST - 1);
+      if (t + NST - 1 < nkt) issue(w, t + NST - 1);
       load_frags(t);
       mma();
     }
@@ -464,119 +519,255 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads of tile t-1 have left LDS
       __builtin_amdgcn_s_barrier();
       if (t > 0) mma();                                     // tile t-1
-      if (t + NST - 1 < nkt) issue(t + NST - 1);
+      if (t + NST - 1 < nkt) issue(w, t + NST - 1);
       load_frags(t);
     }
     if (nkt > 0) mma();                                     // last tile
   }
+  lds_barrier();                                // every wave is done with the operand ring
+  if constexpr (PREFETCH) {
+    const int nxt = item + nblk;
+    pre = nxt < p.total_items;
+    if (pre) {
+      const Item wnx = decode(nxt);
+#pragma unroll
+      for (int t = 0; t < NPRE; ++t)
+        if (t < wnx.nkt) issue(wnx, t);
+    }
+  }
 
-  // ---- epilogue: accumulators -> LDS (f32, one 128-row half at a time) -> row-wise output -----
-  // Fragment-layout stores touch 16 rows x 32 B per instruction and are store-issue bound; going
-  // through LDS every wave instruction writes (or atomically adds) whole row pieces, and bias / GELU /
-  // gelu' / tanh' / residual add run on contiguous 8-element groups with coalesced aux accesses.
-  constexpr int LPR = BN_ / 8;                 // lanes per output row (8 columns each)
-  constexpr int RPI = 64 / LPR;                // rows per wave instruction
-  constexpr int RPW = 128 / NW;                // rows per wave per half
   TC* C = reinterpret_cast<TC*>(p.C);
   TC* AUX = reinterpret_cast<TC*>(p.aux);
-  const bool atomic = (p.ksplit > 1);
-  const bool lead = (zsplit == 0);
-  float* Ct = reinterpret_cast<float*>(smem);   // [128][BN_] f32; 16-B chunk index XOR (row & 7)
-  __syncthreads();                              // every wave is done with the operand ring
-  float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
+  if constexpr (sizeof(TC) == 2) {
+    // ---- bf16 epilogue: bias / activation / activation gradient / residual add run on the accumulators in
+    // the MFMA fragment layout (packed-f32 math, all lanes busy); the finished bf16 values cross LDS (one
+    // 128-row half at a time, 16-B chunk index XOR (row & 15): conflict-free both ways) so that every
+    // global store instruction writes whole 512-byte row pieces.  FCMF_EPI_GELU with an aux pointer makes
+    // two passes per half: pre-activations -> aux, activations -> C.
+    char* stg = smem + (PREFETCH ? NPRE * STAGE_BYTES_ : 0);
+    constexpr int ROWB = BN_ * 2;               // bytes per staged row
+    constexpr int LPR = BN_ / 8;                // lanes per output row (8 columns each)
+    constexpr int RPI = 64 / LPR;               // rows per wave instruction
+    constexpr int RPW = 128 / NW;               // rows per wave per half
+    constexpr int ITS = RPW / RPI;
+    // (the epilogue's per-lane constants are derived from a laundered lane id so that the compiler cannot
+    // hoist them above the main loop, where every VGPR is spoken for)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int er = lane_e & 15, eg = lane_e >> 4;
+    const int colq = wn * 64 + eg * 4;          // + fj * 16: first of the lane's 4 columns in the block tile
+    if (p.bias) {
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) {
+        const int gj = j0 + colq + fj * 16;
+        const f32x4 bq = gj < p.N ? *reinterpret_cast<const f32x4*>(p.bias + gj) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi) acc[fj][fi] = acc[fj][fi] + bq;
+      }
+    }
+    const unsigned ldc2 = (unsigned)p.ldc * 2u;
+    const unsigned abase = (unsigned)er * ldc2 + (unsigned)colq * 2u + (unsigned)(i0 + wm * 128) * ldc2 + (unsigned)j0 * 2u;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.aux ? p.aux : p.C, 0, p.c_bytes, 0x00020000);
+    const bool two_pass = (EPI == FCMF_EPI_GELU) && AUX != nullptr;
+    // Every wave first turns ALL its accumulators into finished bf16 values (straight-line code, all 8 waves
+    // busy, the accumulator registers die as it goes); the staging loops below only move registers.
+    // o1 = the C values, o0 = the pre-activations that FCMF_EPI_GELU also writes to aux.
+    u32x2 o0[EPI == FCMF_EPI_GELU ? 32 : 1], o1[32];
+    auto pack = [&](f32x4 v) __attribute__((always_inline)) -> u32x2 {
+      bf16x4 o;
+      o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+      u32x2 r = __builtin_bit_cast(u32x2, o);
+      asm volatile("" : "+v"(r));            // pins the conversion here (no sinking into / hoisting out of the loops below)
+      return r;
+    };
+    auto finish = [&]() __attribute__((always_inline)) {
+      constexpr bool HAS_AUX = (EPI == FCMF_EPI_DGELU || EPI == FCMF_EPI_ADD);
+      // aux is read in the fragment layout (8 B per lane) through a buffer descriptor: 32-bit offsets, rows
+      // past M read zeros (range check), no exec-mask branches; two fragment rows ahead of their use
+      u32x2 aq[3][4];
+      auto load_aux = [&](int fi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj)
+          aq[fi % 3][fj] = __builtin_amdgcn_raw_buffer_load_b64(rX, abase + (unsigned)(fi * 16) * ldc2 + fj * 32, 0, 0);
+      };
+      if constexpr (HAS_AUX) { load_aux(0); load_aux(1); }
 #pragma unroll
       for (int fi = 0; fi < 8; ++fi) {
-        const int row = fi * 16 + (lane & 15);
+        if constexpr (HAS_AUX) { if (fi + 2 < 8) load_aux(fi + 2); }
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) {
-          const int chunk = wn * 16 + fj * 4 + (lane >> 4);
-          *reinterpret_cast<f32x4*>(Ct + row * BN_ + ((chunk ^ (row & 7)) << 2)) = acc[fj][fi];
-        }
-      }
-    }
-    __syncthreads();
-    if (atomic) {
-      // split-K partial: 256-B contiguous float atomics (one dword per lane, full-rate shape)
-      float* Cf = reinterpret_cast<float*>(C);
-      for (int it = 0; it < RPW; ++it) {
-        const int row = wave * RPW + it, gi = i0 + half * 128 + row;
-        if (gi >= p.M) continue;
-#pragma unroll
-        for (int k = 0; k < BN_ / 64; ++k) {
-          const int col = lane + 64 * k, gj = j0 + col;
-          if (gj < p.N) atomicAdd(Cf + (int64_t)gi * p.ldc + gj, Ct[row * BN_ + ((((col >> 2)) ^ (row & 7)) << 2) + (col & 3)]);
-        }
-      }
-    } else {
-      for (int it = 0; it < RPW / RPI; ++it) {
-        const int row = wave * RPW + it * RPI + lane / LPR, gi = i0 + half * 128 + row;
-        const int c0 = (lane % LPR) * 2, gj = j0 + c0 * 4;
-        if (gi >= p.M || gj >= p.N) continue;
-        float v[8];
-        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(Ct + row * BN_ + ((c0 ^ (row & 7)) << 2));
-        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(Ct + row * BN_ + (((c0 + 1) ^ (row & 7)) << 2));
-        if (p.bias && lead) {
-          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gj), b1 = *reinterpret_cast<const float4*>(p.bias + gj + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        const int64_t off = (int64_t)gi * p.ldc + gj;
-        if (p.epilogue != FCMF_EPI_NONE) {
-          float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (p.epilogue == FCMF_EPI_GELU) {
-            if (AUX) { Vec4<TC>::store(AUX + off, make_float4(v[0], v[1], v[2], v[3])); Vec4<TC>::store(AUX + off + 4, make_float4(v[4], v[5], v[6], v[7])); }
-          } else if (p.epilogue != FCMF_EPI_TANH) {
-            const float4 a0 = Vec4<TC>::load(AUX + off), a1 = Vec4<TC>::load(AUX + off + 4);
-            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+          f32x4 v = acc[fj][fi];
+          if constexpr (EPI == FCMF_EPI_GELU) {
+            o0[fi * 4 + fj] = pack(v);
+            v = v * phi_poly4(v);
+          } else if constexpr (HAS_AUX) {
+            const bf16x4 a4 = __builtin_bit_cast(bf16x4, aq[fi % 3][fj]);
+            const f32x4 a{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+            if constexpr (EPI == FCMF_EPI_ADD) v = v + a;
+            else v = v * dgelu_poly4(a);
           }
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            v[e] = sizeof(TC) == 2 ? apply_epilogue_fast(v[e], p.epilogue, a[e]) : apply_epilogue(v[e], p.epilogue, a[e]);
+          o1[fi * 4 + fj] = pack(v);
         }
-        if constexpr (sizeof(TC) == 4) {
-          float* cf = reinterpret_cast<float*>(C) + off;
+        __builtin_amdgcn_sched_barrier(0);   // one fragment row at a time: short live ranges
+      }
+    };
+    finish();
+    char* wbase = stg + er * ROWB + (eg & 1) * 8;
+    auto stage = [&](const auto& o) __attribute__((always_inline)) {
+#pragma unroll
+      for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+          const int chunk = wn * 8 + fj * 2 + (eg >> 1);
+          *reinterpret_cast<u32x2*>(wbase + fi * 16 * ROWB + ((chunk ^ er) << 4)) = o[fi * 4 + fj];
+        }
+    };
+    const int chunk_r = lane_e % LPR, gj_r = j0 + chunk_r * 8, rsub = lane_e / LPR;
+    const unsigned sbase = gj_r < p.N ? (unsigned)rsub * ldc2 + (unsigned)chunk_r * 16u : 0x80000000u;
+    float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // column sums of the values as stored (bf16-rounded)
+    // whole-row-piece stores through a buffer descriptor: rows past M are dropped by the range check,
+    // lanes past N carry the out-of-range sentinel
+    auto store_rows = [&](int half, void* dstp, bool sums) __attribute__((always_inline)) {
+      const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(dstp, 0, p.c_bytes, 0x00020000);
+      const unsigned srow0 = sbase + (unsigned)(i0 + half * 128 + wave * RPW) * ldc2 + (unsigned)j0 * 2u;
+#pragma unroll
+      for (int it0 = 0; it0 < ITS; it0 += 4) {
+        bf16x8 x[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = wave * RPW + (it0 + it) * RPI + rsub;
+          x[it] = *reinterpret_cast<const bf16x8*>(stg + row * ROWB + ((chunk_r ^ (row & 15)) << 4));
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x[it]), rD, srow0 + (unsigned)((it0 + it) * RPI) * ldc2, 0, 0);
+          if (sums) {
+            const int gi = i0 + half * 128 + wave * RPW + (it0 + it) * RPI + rsub;
+            if (gi < p.M && gj_r < p.N) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) csum[e] += (float)x[it][e];
+            }
+          }
+        }
+      }
+    };
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      if constexpr (EPI == FCMF_EPI_GELU) {
+        if (two_pass) {
+          if (wm == half) stage(o0);
+          lds_barrier();
+          store_rows(half, p.aux, false);
+          lds_barrier();
+        }
+      }
+      if (wm == half) stage(o1);
+      lds_barrier();
+      store_rows(half, p.C, p.colsum != nullptr);
+      lds_barrier();
+    }
+    if (p.colsum) {
+      // a lane owns 8 fixed columns; lanes that differ only above the LPR bits share them.  Reduce the
+      // waves through LDS first: ONE float atomic per column per workgroup.
+      float* red = reinterpret_cast<float*>(stg);    // [NW][BN_]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = csum[e];
+        if (LPR <= 16) t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (lane_e < LPR) red[wave * BN_ + lane_e * 8 + e] = t;
+      }
+      lds_barrier();
+      if (tid < BN_) {
+        float t = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * BN_ + tid];
+        if (j0 + tid < p.N) atomicAdd(p.colsum + j0 + tid, t);
+      }
+      lds_barrier();
+    }
+  } else {
+    // ---- f32 epilogue (weight gradients: accumulate / split-K; epilogue kind is always NONE here):
+    // accumulators -> LDS (f32, one 128-row half at a time) -> row-wise output with whole-row stores or
+    // 256-byte float atomics for split-K
+    constexpr int LPR = BN_ / 8, RPI = 64 / LPR, RPW = 128 / NW;
+    const bool atomic = (p.ksplit > 1);
+    const bool lead = (w.zsplit == 0);
+    float* Ct = reinterpret_cast<float*>(smem);   // [128][BN_] f32; 16-B chunk index XOR (row & 7)
+    const int c0 = (lane % LPR) * 2, gj = j0 + c0 * 4, rsub = lane / LPR;
+    f32x2 csum[4] = {splat2(0.f), splat2(0.f), splat2(0.f), splat2(0.f)};
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      if (wm == half) {
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi) {
+          const int row = fi * 16 + (lane & 15);
+#pragma unroll
+          for (int fj = 0; fj < 4; ++fj) {
+            const int chunk = wn * 16 + fj * 4 + (lane >> 4);
+            *reinterpret_cast<f32x4*>(Ct + row * BN_ + ((chunk ^ (row & 7)) << 2)) = acc[fj][fi];
+          }
+        }
+      }
+      lds_barrier();
+      if (atomic) {
+        float* Cf = reinterpret_cast<float*>(C);
+        for (int it = 0; it < RPW; ++it) {
+          const int row = wave * RPW + it, gi = i0 + half * 128 + row;
+          if (gi >= p.M) continue;
+#pragma unroll
+          for (int k = 0; k < BN_ / 64; ++k) {
+            const int col = lane + 64 * k, gjc = j0 + col;
+            if (gjc < p.N) atomicAdd(Cf + (int64_t)gi * p.ldc + gjc, Ct[row * BN_ + ((((col >> 2)) ^ (row & 7)) << 2) + (col & 3)]);
+          }
+        }
+      } else {
+        f32x2 bv[4] = {splat2(0.f), splat2(0.f), splat2(0.f), splat2(0.f)};
+        if (p.bias && lead && gj < p.N) load8<float>(p.bias + gj, bv);
+#pragma unroll 2
+        for (int it = 0; it < RPW / RPI; ++it) {
+          const int row = wave * RPW + it * RPI + rsub, gi = i0 + half * 128 + row;
+          if (gi >= p.M || gj >= p.N) continue;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(Ct + row * BN_ + ((c0 ^ (row & 7)) << 2));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(Ct + row * BN_ + (((c0 + 1) ^ (row & 7)) << 2));
+          f32x2 v[4] = {f32x2{lo[0], lo[1]} + bv[0], f32x2{lo[2], lo[3]} + bv[1], f32x2{hi[0], hi[1]} + bv[2], f32x2{hi[2], hi[3]} + bv[3]};
+          float* cf = reinterpret_cast<float*>(C) + (int64_t)gi * p.ldc + gj;
           if (p.accumulate) {
-            const float4 o0 = *reinterpret_cast<float4*>(cf), o1 = *reinterpret_cast<float4*>(cf + 4);
-            v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+            f32x2 o[4];
+            load8<float>(cf, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] + o[e];
           }
-          *reinterpret_cast<float4*>(cf) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(cf + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          bf16x8 o;
+          store8<float>(cf, v);
+          if (p.colsum) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x8*>(C + off) = o;
-        }
-        if (p.colsum) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) csum[e] += v[e];
+            for (int e = 0; e < 4; ++e) csum[e] = csum[e] + v[e];
+          }
         }
       }
+      lds_barrier();
     }
-    __syncthreads();
-  }
-  if (p.colsum) {
-    // a lane owns 8 fixed columns; lanes that differ only above the LPR bits share them.  Reduce the
-    // waves through LDS first: ONE float atomic per column per workgroup.
-    float* red = reinterpret_cast<float*>(smem);    // [NW][BN_]
+    if (p.colsum) {
+      // a lane owns 8 fixed columns; lanes that differ only above the LPR bits share them.  Reduce the
+      // waves through LDS first: ONE float atomic per column per workgroup.
+      float* red = reinterpret_cast<float*>(smem);    // [NW][BN_]
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = csum[e];
-      if (LPR <= 16) t += __shfl_xor(t, 16, 64);
-      t += __shfl_xor(t, 32, 64);
-      if (lane < LPR) red[wave * BN_ + lane * 8 + e] = t;
-    }
-    __syncthreads();
-    if (tid < BN_) {
-      float t = 0.f;
+      for (int e = 0; e < 8; ++e) {
+        float t = csum[e >> 1][e & 1];
+        if (LPR <= 16) t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (lane < LPR) red[wave * BN_ + lane * 8 + e] = t;
+      }
+      lds_barrier();
+      if (tid < BN_) {
+        float t = 0.f;
 #pragma unroll
-      for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * BN_ + tid];
-      if (j0 + tid < p.N) atomicAdd(p.colsum + j0 + tid, t);
+        for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * BN_ + tid];
+        if (j0 + tid < p.N) atomicAdd(p.colsum + j0 + tid, t);
+      }
+      lds_barrier();
     }
   }
-    __syncthreads();   // LDS (ring / staging) is reused by the next work item
   }  // work items
 }
 
@@ -724,24 +915,26 @@ static int launch_bf16(const GemmParams& p, int out_dtype, dim3 grid, hipStream_
   return FCMF_OK;
 }
 
-// literal launch bounds per shape (template-dependent bounds are not instantiable on the host)
-template <bool A_TR, bool B_TR, typename TC>
+// literal launch bounds per shape (template-dependent bounds are not instantiable on the host); the
+// epilogue kind is a template parameter: one straight-line epilogue per kernel keeps the register
+// allocation of the main loop clean
+template <bool A_TR, bool B_TR, typename TC, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmParams p) {
-  gemm_bf16_tile_body<A_TR, B_TR, TC, 4, 4>(p);
+  gemm_bf16_tile_body<A_TR, B_TR, TC, EPI, 4, 4>(p);
 }
-template <bool A_TR, bool B_TR, typename TC>
+template <bool A_TR, bool B_TR, typename TC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_tile128n_kernel(GemmParams p) {
-  gemm_bf16_tile_body<A_TR, B_TR, TC, 2, 3>(p);
+  gemm_bf16_tile_body<A_TR, B_TR, TC, EPI, 2, 3>(p);
 }
 
-template <bool A_TR, bool B_TR, typename TC, int WN>
+template <bool A_TR, bool B_TR, typename TC, int EPI, int WN>
 static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
   if constexpr (WN == 4) {
-    auto k = gemm_bf16_tile256_kernel<A_TR, B_TR, TC>;
+    auto k = gemm_bf16_tile256_kernel<A_TR, B_TR, TC, EPI>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
   } else {
-    auto k = gemm_bf16_tile128n_kernel<A_TR, B_TR, TC>;
+    auto k = gemm_bf16_tile128n_kernel<A_TR, B_TR, TC, EPI>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, grid, dim3(256), smem, st, p);
   }
@@ -750,8 +943,13 @@ static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, size_t smem, 
 template <bool A_TR, bool B_TR, int WN, int NST>
 static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st) {
   const size_t smem = (size_t)NST * (A_TILE_BYTES + WN * 64 * BK * 2);
-  if (out_dtype == FCMF_F32) launch_bf16_tile_typed<A_TR, B_TR, float, WN>(p, grid, smem, st);
-  else launch_bf16_tile_typed<A_TR, B_TR, bf16_t, WN>(p, grid, smem, st);
+  if (out_dtype == FCMF_F32) launch_bf16_tile_typed<A_TR, B_TR, float, FCMF_EPI_NONE, WN>(p, grid, smem, st);
+  else switch (p.epilogue) {
+    case FCMF_EPI_NONE: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_NONE, WN>(p, grid, smem, st); break;
+    case FCMF_EPI_GELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_GELU, WN>(p, grid, smem, st); break;
+    case FCMF_EPI_DGELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_DGELU, WN>(p, grid, smem, st); break;
+    default: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_ADD, WN>(p, grid, smem, st); break;
+  }
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
@@ -781,19 +979,23 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
                     (trans_a || K % BK == 0) && (trans_b || K % BK == 0) &&
                     (((int64_t)(trans_a ? K : M) * lda) < (1ll << 30)) && (((int64_t)(trans_b ? K : N) * ldb) < (1ll << 30));
   if (fast) {
-    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, colsum, 0, 0};
+    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, 0, colsum, 0, 0};
     // bytes addressable through each operand: (rows - 1) * ld + contiguous extent
     p.a_bytes = (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
     p.b_bytes = (unsigned)((((int64_t)(trans_b ? K : N) - 1) * ldb + (trans_b ? N : K)) * 2);
+    const int64_t c_extent = (((int64_t)M - 1) * ldc + N) * 2;
+    p.c_bytes = (unsigned)(c_extent < (1ll << 31) ? c_extent : 0);
     const int nk = (K + BK - 1) / BK;
     // tile family: 256x256 (8 waves, 1 workgroup/CU) wherever N allows it; 256x128 (4 waves, 2 workgroups/CU,
     // one hides the other's prologue/epilogue) only for very short K or narrow N -- measured on MI355X the
     // 256x256 ping-pong kernel wins from K = 512 up; 128x128 for small / ragged outputs
     bool large = M >= 256 && N >= 128 && ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && (int64_t)M * N * K >= (1ll << 33))) &&
-                 (N % 8 == 0) && (ldc % 8 == 0);
+                 (N % 8 == 0) && (ldc % 8 == 0) && (out_dtype == FCMF_BF16 || epilogue == FCMF_EPI_NONE) &&
+                 epilogue != FCMF_EPI_TANH && epilogue != FCMF_EPI_DTANH && (out_dtype == FCMF_F32 || c_extent < (1ll << 31));
     int wn = (N >= 256 && nk >= 12) ? 4 : 2;
     if (g_force_tile == 128) large = false;
-    if (g_force_tile == 256 || g_force_tile == 257) { large = (N % 8 == 0) && (ldc % 8 == 0); wn = g_force_tile == 256 ? 4 : 2; }
+    if (g_force_tile == 256 || g_force_tile == 257) { large = (N % 8 == 0) && (ldc % 8 == 0) && (out_dtype == FCMF_BF16 || epilogue == FCMF_EPI_NONE) &&
+              epilogue != FCMF_EPI_TANH && epilogue != FCMF_EPI_DTANH && (out_dtype == FCMF_F32 || c_extent < (1ll << 31)); wn = g_force_tile == 256 ? 4 : 2; }
     if (large) {
       const int bn = wn * 64, slots = wn == 4 ? g_num_cus : 2 * g_num_cus;
       const int tiles_l = ((M + GB - 1) / GB) * ((N + bn - 1) / bn);
