@@ -7,6 +7,20 @@
 //                        (fp32 mode) and odd shapes (classifier N=4, box WG 64->8 ...).
 #include "common.h"
 
+// Diagnostic build only (make TIMING=1 -> tools/bin/timing/libfcmf_hip.so): wave 0 of workgroup 0 stamps the
+// phases of its first work items with the 100 MHz real-time counter.  No stamp exists in the product build.
+#ifdef FCMF_GEMM_TIMING
+__device__ unsigned long long* g_stamp_buf = nullptr;
+extern "C" void fcmf_gemm_timing_buffer(void* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)); }
+#define FCMF_STAMP(k)                                                                                   \
+  do {                                                                                                  \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g_stamp_buf && stamp_item < 16)                          \
+      g_stamp_buf[stamp_item * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                             \
+  } while (0)
+#else
+#define FCMF_STAMP(k) do {} while (0)
+#endif
+
 struct GemmParams {
   const void* A; const void* B; void* C; const float* bias; void* aux;
   int M, N, K;
@@ -293,26 +307,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // =========================================================================================
-// Large-tile kernel family for the big GEMMs of the step.  Every wave owns a 128x64 output tile
-// (32 accumulator fragments of v_mfma_f32_16x16x32_bf16: 12 ds_read_b128 feed 32 MFMAs per k-tile);
-// waves are arranged 2 x WN:
-//   WN = 4: 256x256 block tile, 8 waves, 4-stage LDS-DMA ring (128 KiB, one workgroup per CU),
-//           PING-PONG between the two waves that share a SIMD (see below);
-//   WN = 2: 256x128 block tile, 4 waves, 3-stage ring (72 KiB, TWO workgroups per CU): the second
-//           workgroup's main loop hides this one's prologue / epilogue / barrier skew, which is what
-//           the short-K (K = 768) GEMMs of the layer are bound by.
-// Both are persistent (grid = resident workgroups, each walks the work items tile x k-split), fill the
-// ring with buffer_load_dwordx4 ... lds (swizzle on the source address, range check = zero fill), use a
-// counted vmcnt + ONE raw s_barrier per k-tile, and finish through LDS: accumulators -> f32 staging ->
-// row-wise epilogue (bias, GELU, gelu', tanh', residual add, column sums) with whole-row stores or
-// 256-byte float atomics for split-K.
+// 256x256 kernel for the big GEMMs of the step.  8 waves (2 x 4), every wave owns a 128x64 output tile
+// (32 accumulator fragments of v_mfma_f32_16x16x32_bf16: 12 ds_read_b128 feed 32 MFMAs per k-tile).
+//  * persistent: grid = resident workgroups (one per CU, 160 KiB LDS), each walks the work items
+//    (output tile x k-split) in an XCD-aware order;
+//  * 4-stage LDS ring filled by buffer_load_dwordx4 ... lds (swizzle on the source address, range check =
+//    zero fill), counted vmcnt + ONE raw s_barrier per k-tile; the ring position RUNS ON across work items;
+//  * PING-PONG between the two waves that share a SIMD (see the main loop);
+//  * bf16 outputs: the epilogue is wave-local and barrier-free.  After its last MFMA a wave (1) puts the first
+//    three k-tiles of the NEXT work item in flight (into the three ring stages that are already drained),
+//    (2) turns its accumulators into finished bf16 values in the fragment layout (bias, GELU, gelu', residual
+//    add as packed-f32 math), (3) transposes them through a private 4 KiB LDS slice above the ring and
+//    writes whole 128-byte row pieces with buffer stores.  Waves drift apart
+//    freely; the first barrier of the next item re-aligns them.
+//  * f32 outputs (weight gradients: accumulate / split-K atomics) stage through the whole ring between
+//    barriers: accumulators -> f32 image -> whole-row stores or 256-byte float atomics.
+// The epilogue kind is a template parameter: one straight-line epilogue per kernel keeps the register
+// allocation of the main loop clean (2 waves/SIMD -> 256 VGPRs, 128 of them accumulators).
 // =========================================================================================
-constexpr int GB = 256;                       // block tile rows
-constexpr int A_TILE_BYTES = GB * BK * 2;     // 16 KiB
+constexpr int GB = 256;                       // block tile rows and columns
+constexpr int A_TILE_BYTES = GB * BK * 2;     // 16 KiB per operand tile
+constexpr int TSTAGE_BYTES = 2 * A_TILE_BYTES;
+constexpr int TNST = 4;
 
 template <bool TR>
-__device__ __forceinline__ unsigned dma_voffset_a(int piece, int lane, int64_t ld, int x0, int xdim) {
-  const int q = piece * 64 + lane;             // 16-B slot inside the 16 KiB A tile (1024 slots)
+__device__ __forceinline__ unsigned dma_voffset_t(int piece, int lane, int64_t ld, int x0, int xdim) {
+  const int q = piece * 64 + lane;             // 16-B slot inside the 16 KiB operand tile (1024 slots)
   if (!TR) {
     const int row = q >> 2, c = (q & 3) ^ swz_row(row);
     if (x0 + row >= xdim) return 0x80000000u;
@@ -324,63 +344,29 @@ __device__ __forceinline__ unsigned dma_voffset_a(int piece, int lane, int64_t l
     return (unsigned)(((int64_t)kk * ld + x0 + c16 * 8) * 2);
   }
 }
-template <bool TR, int BN_>
-__device__ __forceinline__ unsigned dma_voffset_b(int piece, int lane, int64_t ld, int x0, int xdim) {
-  const int q = piece * 64 + lane;             // 16-B slot inside the B tile (BN_ * 4 slots)
-  if (!TR) {
-    const int row = q >> 2, c = (q & 3) ^ swz_row(row);
-    if (x0 + row >= xdim) return 0x80000000u;
-    return (unsigned)(((int64_t)(x0 + row) * ld + c * 8) * 2);
-  } else {
-    constexpr int CPR = BN_ / 8;               // 16-B chunks per k row
-    const int kk = q / CPR, cp = q % CPR;
-    const int c16 = ((((cp >> 1) ^ tr_key(kk))) << 1) | (cp & 1);
-    if (x0 + c16 * 8 >= xdim) return 0x80000000u;
-    return (unsigned)(((int64_t)kk * ld + x0 + c16 * 8) * 2);
-  }
-}
 
-template <int E> struct EpiTag { static constexpr int value = E; };
 // 8 consecutive outputs of one row <-> four packed-f32 pairs
-template <typename TC> __device__ __forceinline__ void load8(const TC* q, f32x2 (&v)[4]);
-template <> __device__ __forceinline__ void load8<float>(const float* q, f32x2 (&v)[4]) {
+__device__ __forceinline__ void load8f(const float* q, f32x2 (&v)[4]) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(q), b = *reinterpret_cast<const f32x4*>(q + 4);
   v[0] = f32x2{a[0], a[1]}; v[1] = f32x2{a[2], a[3]}; v[2] = f32x2{b[0], b[1]}; v[3] = f32x2{b[2], b[3]};
 }
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* q, f32x2 (&v)[4]) {
-  const bf16x8 a = *reinterpret_cast<const bf16x8*>(q);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = f32x2{(float)a[2 * e], (float)a[2 * e + 1]};
-}
-template <typename TC> __device__ __forceinline__ void store8(TC* q, const f32x2 (&v)[4]);
-template <> __device__ __forceinline__ void store8<float>(float* q, const f32x2 (&v)[4]) {
+__device__ __forceinline__ void store8f(float* q, const f32x2 (&v)[4]) {
   *reinterpret_cast<f32x4*>(q) = f32x4{v[0][0], v[0][1], v[1][0], v[1][1]};
   *reinterpret_cast<f32x4*>(q + 4) = f32x4{v[2][0], v[2][1], v[3][0], v[3][1]};
 }
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* q, const f32x2 (&v)[4]) {
-  bf16x8 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { o[2 * e] = (bf16_t)v[e][0]; o[2 * e + 1] = (bf16_t)v[e][1]; }
-  *reinterpret_cast<bf16x8*>(q) = o;
-}
 
-template <bool A_TR, bool B_TR, typename TC, int EPI, int WN, int NST>
-__device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
-  constexpr int NW = 2 * WN;                   // waves
-  constexpr int BN_ = WN * 64;                 // block tile columns
-  constexpr int B_TILE_BYTES = BN_ * BK * 2;
-  constexpr int STAGE_BYTES_ = A_TILE_BYTES + B_TILE_BYTES;
-  constexpr int A_PIECES = 16 / NW, B_PIECES = (B_TILE_BYTES / 1024) / NW, PIECES = A_PIECES + B_PIECES;
-  constexpr int B_ROW = BN_ * 2;               // bytes per k row of a transposed B tile
+template <bool A_TR, bool B_TR, typename TC, int EPI>
+__device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
+  constexpr int NW = 8;
+  constexpr int A_PIECES = 2, B_PIECES = 2;    // 1 KiB DMA pieces per wave per operand tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;    // rows wm*128, cols wn*64
+  const int wm = wave >> 2, wn = wave & 3;     // rows wm*128, cols wn*64
 
-  // PERSISTENT workgroups: each walks the work items (output tile x k-split) round by round.
   // XCD-aware order inside a round: the workgroups of one XCD (blockIdx % 8) take consecutive logical
   // items, and consecutive items share the A row-panel (all N tiles of one M tile) -> L2 hits.
-  const int tiles_n = (p.N + BN_ - 1) / BN_;
+  const int tiles_n = (p.N + GB - 1) / GB;
   const int nblk = gridDim.x;
   int slot = blockIdx.x;
   {
@@ -400,7 +386,7 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
   const int trk = tr_key(8 * g4 + q4);
   const int tr_col = ((p4 >> 1) << 4) + ((p4 & 1) << 3);
   const int a_lane = A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * 128 * 64;
-  const int b_lane = A_TILE_BYTES + (B_TR ? (8 * g4 + q4) * B_ROW + tr_col : row_base + wn * 64 * 64);
+  const int b_lane = A_TILE_BYTES + (B_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wn * 64 * 64);
   auto frag_a = [&](const char* st, int f) -> bf16x8 {     // f = 0..7: 16-row fragment of this wave's 128 rows
     if (!A_TR) return *reinterpret_cast<const bf16x8*>(st + a_lane + f * 1024);
     const char* q = st + a_lane + (((wm * 8 + f) ^ trk) << 5);
@@ -414,7 +400,7 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
     if (!B_TR) return *reinterpret_cast<const bf16x8*>(st + b_lane + f * 1024);
     const char* q = st + b_lane + (((wn * 4 + f) ^ trk) << 5);
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * B_ROW));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * 512));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
@@ -425,54 +411,65 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
     const int zsplit = item / p.tiles, tile = item - zsplit * p.tiles;
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int kb = zsplit * p.ktiles_per_split;
-    return Item{tile_m * GB, tile_n * BN_, kb, min(nk_total, kb + p.ktiles_per_split) - kb, zsplit};
+    return Item{tile_m * GB, tile_n * GB, kb, min(nk_total, kb + p.ktiles_per_split) - kb, zsplit};
   };
-  auto stage_ptr = [&](int t) { return smem + (t % NST) * STAGE_BYTES_; };
-  // DMA of k-tile t (relative to the item's first) into ring stage t % NST; (i0, j0) -> per-lane source offsets
-  auto issue = [&](const Item& w, int t) {
-    char* st = stage_ptr(t);
+  // ring: k-tile t of the current item lives in stage (base + t) % 4; `base` runs on across items
+  int base = 0;
+  auto stage_at = [&](int s) { return smem + (s & (TNST - 1)) * TSTAGE_BYTES; };
+  // per-lane DMA source offsets of an item's operand tiles (k-tile 0): computed ONCE per item
+  struct Src { unsigned a[A_PIECES], b[B_PIECES]; };
+  auto sources = [&](const Item& w) -> Src {
+    Src r;
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR>(wave * A_PIECES + j, lane, p.lda, w.i0, p.M);
+#pragma unroll
+    for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
+    return r;
+  };
+  // DMA of k-tile t of item w into ring stage s
+  auto issue = [&](const Item& w, const Src& src, int t, int s) {
+    char* st = stage_at(s);
     const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
       char* d = st + (wave * A_PIECES + j) * 1024;
-      const unsigned va = dma_voffset_a<A_TR>(wave * A_PIECES + j, lane, p.lda, w.i0, p.M);
-      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va + ka, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va, ka, 0, 0);
+      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j] + ka, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j], ka, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j) {
       char* d = st + A_TILE_BYTES + (wave * B_PIECES + j) * 1024;
-      const unsigned vb = dma_voffset_b<B_TR, BN_>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
-      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb + kb, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb, kb, 0, 0);
+      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, src.b[j] + kb, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, src.b[j], kb, 0, 0);
     }
   };
   auto lds_barrier = [&]() {   // LDS traffic of this wave retired, then the workgroup barrier; global stores stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
-  // bf16 outputs stage through HALF the ring, so the first NPRE k-tiles of the NEXT work item are put in
-  // flight before the epilogue starts (their DMA latency hides under it)
-  constexpr bool PREFETCH = (WN == 4) && sizeof(TC) == 2;
-  constexpr int NPRE = 2;
+  constexpr bool PREFETCH = sizeof(TC) == 2;   // bf16 epilogue leaves the ring alone -> next item's tiles 0, 1 fly under it
   bool pre = false;
 
   for (int item = slot; item < p.total_items; item += nblk) {
   const Item w = decode(item);
+  Src src = sources(w);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(src.a[j]), "+v"(src.b[j]));   // materialised here, not re-derived per k-tile
   const int i0 = w.i0, j0 = w.j0, nkt = w.nkt;
-  // own DMAs of tile t have landed once at most `younger` later tiles (PIECES DMAs each) are outstanding
-  // (loads retire in order; stores of the previous epilogue that are still in flight only make the wait longer)
+  [[maybe_unused]] const int stamp_item = (item - slot) / nblk;
+  FCMF_STAMP(0);
+  // Issue schedule: tiles 0, 1, 2 before the loop (or already in flight from the previous epilogue), tile t + 3
+  // after barrier t.  Own DMAs of tile t have landed once at most the two younger tiles (4 DMAs each) are
+  // outstanding: loads retire in order, and stores of the previous epilogue that are still in flight only
+  // make the wait longer.
   auto wait_landed = [&](int t) {
-    int younger = nkt - 1 - t;
-    if (younger > NST - 2) younger = NST - 2;
-    if (PIECES == 4) {
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    const int younger = nkt - 1 - t;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto issue_after_barrier = [&](int t) {
+    if (t + 3 < nkt) issue(w, src, t + 3, base + t + 3);
   };
 
   f32x4 acc[4][8];  // [j frag][i frag]
@@ -482,7 +479,7 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 fa[8], fb[4];
   auto load_frags = [&](int t) {
-    const char* st = stage_ptr(t);
+    const char* st = stage_at(base + t);
 #pragma unroll
     for (int f = 0; f < 4; ++f) fb[f] = frag_b(st, f);
 #pragma unroll
@@ -497,19 +494,25 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
         acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[fj], fa[fi], acc[fj][fi], 0, 0, 0);
   };
 
-#pragma unroll
-  for (int t = 0; t < NST - 1; ++t)
-    if (t < nkt && !(pre && t < NPRE)) issue(w, t);
-  // PING-PONG (8-wave variant): waves w and w+4 share a SIMD.  Between barrier t and barrier t+1
-  // group A (waves 0-3) feeds (DMA tile t+3, fragment reads of tile t) THEN multiplies tile t, while
-  // group B (waves 4-7) multiplies tile t-1 FIRST (fragments read in the previous interval) and feeds
-  // tile t afterwards: the SIMD's matrix pipe sees A's 32 MFMAs while B feeds and vice versa.
-  const bool group_b = (WN == 4) && wave >= 4;     // wave is an SGPR: a uniform branch
+  if (!pre) {
+    issue(w, src, 0, base);
+    if (1 < nkt) issue(w, src, 1, base + 1);
+    if (2 < nkt) issue(w, src, 2, base + 2);
+  }
+  // PING-PONG: waves w and w+4 share a SIMD.  Between barrier t and barrier t+1 group A (waves 0-3) feeds
+  // (DMA, fragment reads of tile t) THEN multiplies tile t, while group B (waves 4-7) multiplies tile t-1
+  // FIRST (fragments read in the previous interval) and feeds tile t afterwards: the SIMD's matrix pipe
+  // sees A's 32 MFMAs while B feeds and vice versa.
+  const bool group_b = wave >= 4;              // wave is an SGPR: a uniform branch
   if (!group_b) {
     for (int t = 0; t < nkt; ++t) {
       wait_landed(t);
       __builtin_amdgcn_s_barrier();            // tile t visible; the stage of tile t-1 is no longer read
-      if (t + NST - 1 < nkt) issue(w, t + NST - 1);
+#ifdef FCMF_GEMM_TIMING
+      if (t == 0) FCMF_STAMP(1);
+      if (t == 8) FCMF_STAMP(6);
+#endif
+      issue_after_barrier(t);
       load_frags(t);
       mma();
     }
@@ -519,193 +522,200 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads of tile t-1 have left LDS
       __builtin_amdgcn_s_barrier();
       if (t > 0) mma();                                     // tile t-1
-      if (t + NST - 1 < nkt) issue(w, t + NST - 1);
+      issue_after_barrier(t);
       load_frags(t);
     }
-    if (nkt > 0) mma();                                     // last tile
+    mma();                                                  // last tile (nkt >= 1 always)
   }
-  lds_barrier();                                // every wave is done with the operand ring
-  if constexpr (PREFETCH) {
-    const int nxt = item + nblk;
-    pre = nxt < p.total_items;
-    if (pre) {
-      const Item wnx = decode(nxt);
-#pragma unroll
-      for (int t = 0; t < NPRE; ++t)
-        if (t < wnx.nkt) issue(wnx, t);
-    }
-  }
+  FCMF_STAMP(2);
+  const int nbase = base + nkt;                 // ring position of the next item's tile 0
 
   TC* C = reinterpret_cast<TC*>(p.C);
-  TC* AUX = reinterpret_cast<TC*>(p.aux);
   if constexpr (sizeof(TC) == 2) {
-    // ---- bf16 epilogue: bias / activation / activation gradient / residual add run on the accumulators in
-    // the MFMA fragment layout (packed-f32 math, all lanes busy); the finished bf16 values cross LDS (one
-    // 128-row half at a time, 16-B chunk index XOR (row & 15): conflict-free both ways) so that every
-    // global store instruction writes whole 512-byte row pieces.  FCMF_EPI_GELU with an aux pointer makes
-    // two passes per half: pre-activations -> aux, activations -> C.
-    char* stg = smem + (PREFETCH ? NPRE * STAGE_BYTES_ : 0);
-    constexpr int ROWB = BN_ * 2;               // bytes per staged row
-    constexpr int LPR = BN_ / 8;                // lanes per output row (8 columns each)
-    constexpr int RPI = 64 / LPR;               // rows per wave instruction
-    constexpr int RPW = 128 / NW;               // rows per wave per half
-    constexpr int ITS = RPW / RPI;
-    // (the epilogue's per-lane constants are derived from a laundered lane id so that the compiler cannot
-    // hoist them above the main loop, where every VGPR is spoken for)
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
+    // ---- wave-local bf16 epilogue ------------------------------------------------------------------
+    // Every wave of the workgroup has passed barrier nkt-1, so every stage except that of tile nkt-1
+    // (= nbase + 3) is drained: nbase + 0 / 1 / 2 take the next item's tiles 0 / 1 / 2 now (tile 3 follows
+    // after ITS barrier 0, the regular schedule).  The 32 KiB above the ring hold a private 4 KiB
+    // transposition slice per wave ([32 rows][64 columns] bf16, 16-B chunk ^ ((row >> 1) & 7): conflict-free
+    // both ways), so the epilogue never touches the ring.
+    int lane_e = lane;                          // (laundered: keeps the epilogue's per-lane constants from being
+    asm volatile("" : "+v"(lane_e));            //  hoisted above the main loop, where every VGPR is spoken for)
     const int er = lane_e & 15, eg = lane_e >> 4;
-    const int colq = wn * 64 + eg * 4;          // + fj * 16: first of the lane's 4 columns in the block tile
+    const unsigned ldc2 = (unsigned)p.ldc * 2u;
+    const unsigned tile_off = (unsigned)(i0 + wm * 128) * ldc2 + (unsigned)(j0 + wn * 64) * 2u;   // wave's sub-tile
+    constexpr bool HAS_AUX = (EPI == FCMF_EPI_DGELU || EPI == FCMF_EPI_ADD);
+    // transposition slice: fragment-layout accesses are 8 B per lane, row-layout accesses 16 B per lane (whole
+    // 128-B row pieces, 8 rows per instruction); LDS executes a wave's accesses in order
+    char* slice = smem + TNST * TSTAGE_BYTES + wave * 4096;
+    char* wbase = slice + er * 128 + (eg & 1) * 8;
+    auto frag_addr = [&](int h, int fj) __attribute__((always_inline)) -> char* {   // fragment (row block h of the round, fj)
+      const int row = h * 16 + er, chunk = fj * 2 + (eg >> 1);
+      return wbase + h * 16 * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    };
+    const int rrow = lane_e >> 3, rchunk = lane_e & 7;          // row-layout lane mapping
+    auto row_addr = [&](int it) __attribute__((always_inline)) -> char* {
+      const int row = it * 8 + rrow;
+      return slice + row * 128 + ((rchunk ^ ((row >> 1) & 7)) << 4);
+    };
+    // global side of the row layout through buffer descriptors: 32-bit offsets, rows past M are dropped / read
+    // as zeros by the range check, lanes past N carry the out-of-range sentinel -- no exec-mask branches
+    const int gj_r = j0 + wn * 64 + rchunk * 8;
+    const unsigned sbase = gj_r < p.N ? tile_off + (unsigned)rrow * ldc2 + (unsigned)rchunk * 16u : 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.c_bytes, 0x00020000);
+    // aux (gelu' argument / residual) arrives in the row layout too (full cache lines; a fragment-layout global
+    // read would touch 16 lines per instruction), two 32-row rounds ahead of its use, and is turned into the
+    // fragment layout through the slice
+    [[maybe_unused]] u32x4 ax[2][HAS_AUX ? 4 : 1];
+    auto load_aux = [&](int rnd) __attribute__((always_inline)) {
+      if constexpr (HAS_AUX) {
+        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, p.c_bytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          ax[rnd & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rX, sbase + (unsigned)(rnd * 32 + it * 8) * ldc2, 0, 0);
+      }
+    };
+    load_aux(0);
+    load_aux(1);
+    if constexpr (PREFETCH) {
+      const int nxt = item + nblk;
+      pre = nxt < p.total_items;
+      if (pre) {
+        const Item wnx = decode(nxt);
+        const Src snx = sources(wnx);
+        issue(wnx, snx, 0, nbase);
+        if (1 < wnx.nkt) issue(wnx, snx, 1, nbase + 1);
+        if (2 < wnx.nkt) issue(wnx, snx, 2, nbase + 2);
+      }
+    }
+    FCMF_STAMP(3);
     if (p.bias) {
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) {
-        const int gj = j0 + colq + fj * 16;
+        const int gj = j0 + wn * 64 + eg * 4 + fj * 16;
         const f32x4 bq = gj < p.N ? *reinterpret_cast<const f32x4*>(p.bias + gj) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int fi = 0; fi < 8; ++fi) acc[fj][fi] = acc[fj][fi] + bq;
       }
     }
-    const unsigned ldc2 = (unsigned)p.ldc * 2u;
-    const unsigned abase = (unsigned)er * ldc2 + (unsigned)colq * 2u + (unsigned)(i0 + wm * 128) * ldc2 + (unsigned)j0 * 2u;
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.aux ? p.aux : p.C, 0, p.c_bytes, 0x00020000);
-    const bool two_pass = (EPI == FCMF_EPI_GELU) && AUX != nullptr;
-    // Every wave first turns ALL its accumulators into finished bf16 values (straight-line code, all 8 waves
-    // busy, the accumulator registers die as it goes); the staging loops below only move registers.
-    // o1 = the C values, o0 = the pre-activations that FCMF_EPI_GELU also writes to aux.
-    u32x2 o0[EPI == FCMF_EPI_GELU ? 32 : 1], o1[32];
     auto pack = [&](f32x4 v) __attribute__((always_inline)) -> u32x2 {
       bf16x4 o;
       o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
       u32x2 r = __builtin_bit_cast(u32x2, o);
-      asm volatile("" : "+v"(r));            // pins the conversion here (no sinking into / hoisting out of the loops below)
+      asm volatile("" : "+v"(r));            // pins the conversion here (no sinking into the loops below)
       return r;
     };
-    auto finish = [&]() __attribute__((always_inline)) {
-      constexpr bool HAS_AUX = (EPI == FCMF_EPI_DGELU || EPI == FCMF_EPI_ADD);
-      // aux is read in the fragment layout (8 B per lane) through a buffer descriptor: 32-bit offsets, rows
-      // past M read zeros (range check), no exec-mask branches; two fragment rows ahead of their use
-      u32x2 aq[3][4];
-      auto load_aux = [&](int fi) __attribute__((always_inline)) {
+    float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // column sums of the values as stored (bf16-rounded)
+    // rows of the slice -> global (16 B per lane), optionally summing the columns
+    auto store_round = [&](int rnd, const __amdgpu_buffer_rsrc_t& rD, bool sums) __attribute__((always_inline)) {
+      bf16x8 x[4];
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj)
-          aq[fi % 3][fj] = __builtin_amdgcn_raw_buffer_load_b64(rX, abase + (unsigned)(fi * 16) * ldc2 + fj * 32, 0, 0);
-      };
-      if constexpr (HAS_AUX) { load_aux(0); load_aux(1); }
+      for (int it = 0; it < 4; ++it) x[it] = *reinterpret_cast<const bf16x8*>(row_addr(it));
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x[it]), rD, sbase + (unsigned)(rnd * 32 + it * 8) * ldc2, 0, 0);
+        if (sums) {
+          const int gi = i0 + wm * 128 + rnd * 32 + it * 8 + rrow;
+          if (gi < p.M) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += (float)x[it][e];
+          }
+        }
+      }
+    };
+    if constexpr (HAS_AUX) {
+      // round by round (32 rows): aux rows -> slice -> fragment layout, math, results -> slice -> rows -> C
+#pragma unroll
+      for (int rnd = 0; rnd < 4; ++rnd) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(row_addr(it)) = ax[rnd & 1][it];
+        if (rnd + 2 < 4) load_aux(rnd + 2);
+        u32x2 o[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int fj = 0; fj < 4; ++fj) {
+            const bf16x4 a4 = __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2*>(frag_addr(h, fj)));
+            const f32x4 a{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+            f32x4 v = acc[fj][rnd * 2 + h];
+            if constexpr (EPI == FCMF_EPI_ADD) v = v + a;
+            else v = v * dgelu_poly4(a);
+            o[h * 4 + fj] = pack(v);
+          }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int fj = 0; fj < 4; ++fj) *reinterpret_cast<u32x2*>(frag_addr(h, fj)) = o[h * 4 + fj];
+        store_round(rnd, rC, p.colsum != nullptr);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      FCMF_STAMP(4);
+    } else {
+      const bool two_pass = (EPI == FCMF_EPI_GELU) && p.aux != nullptr;
+      // accumulators -> finished bf16 values (straight-line code; the accumulator registers die as it goes).
+      // o1 = the C values, o0 = the pre-activations that FCMF_EPI_GELU also writes to aux.
+      u32x2 o0[EPI == FCMF_EPI_GELU ? 32 : 1], o1[32];
 #pragma unroll
       for (int fi = 0; fi < 8; ++fi) {
-        if constexpr (HAS_AUX) { if (fi + 2 < 8) load_aux(fi + 2); }
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) {
           f32x4 v = acc[fj][fi];
           if constexpr (EPI == FCMF_EPI_GELU) {
             o0[fi * 4 + fj] = pack(v);
             v = v * phi_poly4(v);
-          } else if constexpr (HAS_AUX) {
-            const bf16x4 a4 = __builtin_bit_cast(bf16x4, aq[fi % 3][fj]);
-            const f32x4 a{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
-            if constexpr (EPI == FCMF_EPI_ADD) v = v + a;
-            else v = v * dgelu_poly4(a);
           }
           o1[fi * 4 + fj] = pack(v);
         }
         __builtin_amdgcn_sched_barrier(0);   // one fragment row at a time: short live ranges
       }
-    };
-    finish();
-    char* wbase = stg + er * ROWB + (eg & 1) * 8;
-    auto stage = [&](const auto& o) __attribute__((always_inline)) {
+      FCMF_STAMP(4);
+      auto write_out = [&](const auto& o, const __amdgpu_buffer_rsrc_t& rD, bool sums) __attribute__((always_inline)) {
 #pragma unroll
-      for (int fi = 0; fi < 8; ++fi)
+        for (int rnd = 0; rnd < 4; ++rnd) {
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
-          const int chunk = wn * 8 + fj * 2 + (eg >> 1);
-          *reinterpret_cast<u32x2*>(wbase + fi * 16 * ROWB + ((chunk ^ er) << 4)) = o[fi * 4 + fj];
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int fj = 0; fj < 4; ++fj) *reinterpret_cast<u32x2*>(frag_addr(h, fj)) = o[(rnd * 2 + h) * 4 + fj];
+          store_round(rnd, rD, sums);
         }
-    };
-    const int chunk_r = lane_e % LPR, gj_r = j0 + chunk_r * 8, rsub = lane_e / LPR;
-    const unsigned sbase = gj_r < p.N ? (unsigned)rsub * ldc2 + (unsigned)chunk_r * 16u : 0x80000000u;
-    float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // column sums of the values as stored (bf16-rounded)
-    // whole-row-piece stores through a buffer descriptor: rows past M are dropped by the range check,
-    // lanes past N carry the out-of-range sentinel
-    auto store_rows = [&](int half, void* dstp, bool sums) __attribute__((always_inline)) {
-      const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(dstp, 0, p.c_bytes, 0x00020000);
-      const unsigned srow0 = sbase + (unsigned)(i0 + half * 128 + wave * RPW) * ldc2 + (unsigned)j0 * 2u;
-#pragma unroll
-      for (int it0 = 0; it0 < ITS; it0 += 4) {
-        bf16x8 x[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int row = wave * RPW + (it0 + it) * RPI + rsub;
-          x[it] = *reinterpret_cast<const bf16x8*>(stg + row * ROWB + ((chunk_r ^ (row & 15)) << 4));
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x[it]), rD, srow0 + (unsigned)((it0 + it) * RPI) * ldc2, 0, 0);
-          if (sums) {
-            const int gi = i0 + half * 128 + wave * RPW + (it0 + it) * RPI + rsub;
-            if (gi < p.M && gj_r < p.N) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) csum[e] += (float)x[it][e];
-            }
-          }
-        }
-      }
-    };
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+      };
       if constexpr (EPI == FCMF_EPI_GELU) {
-        if (two_pass) {
-          if (wm == half) stage(o0);
-          lds_barrier();
-          store_rows(half, p.aux, false);
-          lds_barrier();
-        }
+        if (two_pass) write_out(o0, __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, p.c_bytes, 0x00020000), false);
       }
-      if (wm == half) stage(o1);
-      lds_barrier();
-      store_rows(half, p.C, p.colsum != nullptr);
-      lds_barrier();
+      write_out(o1, rC, p.colsum != nullptr);
     }
     if (p.colsum) {
-      // a lane owns 8 fixed columns; lanes that differ only above the LPR bits share them.  Reduce the
-      // waves through LDS first: ONE float atomic per column per workgroup.
-      float* red = reinterpret_cast<float*>(stg);    // [NW][BN_]
+      // a lane owns 8 fixed columns for the rows it visited; lanes that share (lane & 7) share the columns
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = csum[e];
-        if (LPR <= 16) t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        if (lane_e < LPR) red[wave * BN_ + lane_e * 8 + e] = t;
+        t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+        if (lane_e < 8 && gj_r < p.N) atomicAdd(p.colsum + gj_r + e, t);
       }
-      lds_barrier();
-      if (tid < BN_) {
-        float t = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * BN_ + tid];
-        if (j0 + tid < p.N) atomicAdd(p.colsum + j0 + tid, t);
-      }
-      lds_barrier();
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice reads have returned before the wave moves on
   } else {
     // ---- f32 epilogue (weight gradients: accumulate / split-K; epilogue kind is always NONE here):
-    // accumulators -> LDS (f32, one 128-row half at a time) -> row-wise output with whole-row stores or
-    // 256-byte float atomics for split-K
-    constexpr int LPR = BN_ / 8, RPI = 64 / LPR, RPW = 128 / NW;
+    // accumulators -> LDS (f32, one 128-row half at a time, the whole ring) -> row-wise output with
+    // whole-row stores or 256-byte float atomics for split-K
+    constexpr int LPR = GB / 8, RPI = 64 / LPR, RPW = 128 / NW;
     const bool atomic = (p.ksplit > 1);
     const bool lead = (w.zsplit == 0);
-    float* Ct = reinterpret_cast<float*>(smem);   // [128][BN_] f32; 16-B chunk index XOR (row & 7)
-    const int c0 = (lane % LPR) * 2, gj = j0 + c0 * 4, rsub = lane / LPR;
+    float* Ct = reinterpret_cast<float*>(smem);   // [128][256] f32; 16-B chunk index XOR (row & 7)
+    int lane_e = lane;                          // (laundered, as in the bf16 epilogue)
+    asm volatile("" : "+v"(lane_e));
+    const int c0 = (lane_e % LPR) * 2, gj = j0 + c0 * 4, rsub = lane_e / LPR;
     f32x2 csum[4] = {splat2(0.f), splat2(0.f), splat2(0.f), splat2(0.f)};
+    lds_barrier();                                // every wave is done with the operand ring
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       if (wm == half) {
 #pragma unroll
         for (int fi = 0; fi < 8; ++fi) {
-          const int row = fi * 16 + (lane & 15);
+          const int row = fi * 16 + (lane_e & 15);
 #pragma unroll
           for (int fj = 0; fj < 4; ++fj) {
-            const int chunk = wn * 16 + fj * 4 + (lane >> 4);
-            *reinterpret_cast<f32x4*>(Ct + row * BN_ + ((chunk ^ (row & 7)) << 2)) = acc[fj][fi];
+            const int chunk = wn * 16 + fj * 4 + (lane_e >> 4);
+            *reinterpret_cast<f32x4*>(Ct + row * GB + ((chunk ^ (row & 7)) << 2)) = acc[fj][fi];
           }
         }
       }
@@ -716,29 +726,29 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
           const int row = wave * RPW + it, gi = i0 + half * 128 + row;
           if (gi >= p.M) continue;
 #pragma unroll
-          for (int k = 0; k < BN_ / 64; ++k) {
-            const int col = lane + 64 * k, gjc = j0 + col;
-            if (gjc < p.N) atomicAdd(Cf + (int64_t)gi * p.ldc + gjc, Ct[row * BN_ + ((((col >> 2)) ^ (row & 7)) << 2) + (col & 3)]);
+          for (int k = 0; k < GB / 64; ++k) {
+            const int col = lane_e + 64 * k, gjc = j0 + col;
+            if (gjc < p.N) atomicAdd(Cf + (int64_t)gi * p.ldc + gjc, Ct[row * GB + ((((col >> 2)) ^ (row & 7)) << 2) + (col & 3)]);
           }
         }
       } else {
         f32x2 bv[4] = {splat2(0.f), splat2(0.f), splat2(0.f), splat2(0.f)};
-        if (p.bias && lead && gj < p.N) load8<float>(p.bias + gj, bv);
+        if (p.bias && lead && gj < p.N) load8f(p.bias + gj, bv);
 #pragma unroll 2
         for (int it = 0; it < RPW / RPI; ++it) {
           const int row = wave * RPW + it * RPI + rsub, gi = i0 + half * 128 + row;
           if (gi >= p.M || gj >= p.N) continue;
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(Ct + row * BN_ + ((c0 ^ (row & 7)) << 2));
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(Ct + row * BN_ + (((c0 + 1) ^ (row & 7)) << 2));
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(Ct + row * GB + ((c0 ^ (row & 7)) << 2));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(Ct + row * GB + (((c0 + 1) ^ (row & 7)) << 2));
           f32x2 v[4] = {f32x2{lo[0], lo[1]} + bv[0], f32x2{lo[2], lo[3]} + bv[1], f32x2{hi[0], hi[1]} + bv[2], f32x2{hi[2], hi[3]} + bv[3]};
           float* cf = reinterpret_cast<float*>(C) + (int64_t)gi * p.ldc + gj;
           if (p.accumulate) {
             f32x2 o[4];
-            load8<float>(cf, o);
+            load8f(cf, o);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] + o[e];
           }
-          store8<float>(cf, v);
+          store8f(cf, v);
           if (p.colsum) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) csum[e] = csum[e] + v[e];
@@ -750,24 +760,25 @@ __device__ __forceinline__ void gemm_bf16_tile_body(const GemmParams& p) {
     if (p.colsum) {
       // a lane owns 8 fixed columns; lanes that differ only above the LPR bits share them.  Reduce the
       // waves through LDS first: ONE float atomic per column per workgroup.
-      float* red = reinterpret_cast<float*>(smem);    // [NW][BN_]
+      float* red = reinterpret_cast<float*>(smem);    // [NW][256]
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = csum[e >> 1][e & 1];
-        if (LPR <= 16) t += __shfl_xor(t, 16, 64);
         t += __shfl_xor(t, 32, 64);
-        if (lane < LPR) red[wave * BN_ + lane * 8 + e] = t;
+        if (lane_e < LPR) red[wave * GB + lane_e * 8 + e] = t;
       }
       lds_barrier();
-      if (tid < BN_) {
+      if (tid < GB) {
         float t = 0.f;
 #pragma unroll
-        for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * BN_ + tid];
+        for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * GB + tid];
         if (j0 + tid < p.N) atomicAdd(p.colsum + j0 + tid, t);
       }
       lds_barrier();
     }
   }
+  base = nbase & (TNST - 1);
+  FCMF_STAMP(5);
   }  // work items
 }
 
@@ -915,46 +926,35 @@ static int launch_bf16(const GemmParams& p, int out_dtype, dim3 grid, hipStream_
   return FCMF_OK;
 }
 
-// literal launch bounds per shape (template-dependent bounds are not instantiable on the host); the
-// epilogue kind is a template parameter: one straight-line epilogue per kernel keeps the register
-// allocation of the main loop clean
+// (thin __global__ wrapper: the body holds AMDGPU inline-asm constraints, which the host pass must never see
+// inside a kernel template -- it would silently drop the host-side kernel handle)
 template <bool A_TR, bool B_TR, typename TC, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmParams p) {
-  gemm_bf16_tile_body<A_TR, B_TR, TC, EPI, 4, 4>(p);
+  gemm_bf16_tile256_body<A_TR, B_TR, TC, EPI>(p);
 }
+
 template <bool A_TR, bool B_TR, typename TC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_tile128n_kernel(GemmParams p) {
-  gemm_bf16_tile_body<A_TR, B_TR, TC, EPI, 2, 3>(p);
+static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, hipStream_t st) {
+  const size_t smem = (size_t)TNST * TSTAGE_BYTES + 8 * 4096;   // ring + per-wave transposition slices = 160 KiB
+  auto k = gemm_bf16_tile256_kernel<A_TR, B_TR, TC, EPI>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
 }
 
-template <bool A_TR, bool B_TR, typename TC, int EPI, int WN>
-static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, size_t smem, hipStream_t st) {
-  if constexpr (WN == 4) {
-    auto k = gemm_bf16_tile256_kernel<A_TR, B_TR, TC, EPI>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
-  } else {
-    auto k = gemm_bf16_tile128n_kernel<A_TR, B_TR, TC, EPI>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, p);
-  }
-}
-
-template <bool A_TR, bool B_TR, int WN, int NST>
+template <bool A_TR, bool B_TR>
 static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st) {
-  const size_t smem = (size_t)NST * (A_TILE_BYTES + WN * 64 * BK * 2);
-  if (out_dtype == FCMF_F32) launch_bf16_tile_typed<A_TR, B_TR, float, FCMF_EPI_NONE, WN>(p, grid, smem, st);
+  if (out_dtype == FCMF_F32) launch_bf16_tile_typed<A_TR, B_TR, float, FCMF_EPI_NONE>(p, grid, st);
   else switch (p.epilogue) {
-    case FCMF_EPI_NONE: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_NONE, WN>(p, grid, smem, st); break;
-    case FCMF_EPI_GELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_GELU, WN>(p, grid, smem, st); break;
-    case FCMF_EPI_DGELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_DGELU, WN>(p, grid, smem, st); break;
-    default: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_ADD, WN>(p, grid, smem, st); break;
+    case FCMF_EPI_NONE: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_NONE>(p, grid, st); break;
+    case FCMF_EPI_GELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_GELU>(p, grid, st); break;
+    case FCMF_EPI_DGELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_DGELU>(p, grid, st); break;
+    default: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_ADD>(p, grid, st); break;
   }
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
 static int g_num_cus = 256;    // MI355X: 8 XCDs x 32 CUs; one persistent 128-KiB-LDS workgroup per CU
-static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced (benchmarks, tests)
+static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced kernel (benchmarks, tests)
 extern "C" void fcmf_gemm_force_tile(int tile) { g_force_tile = tile; }
 
 extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum, int M,
@@ -986,19 +986,18 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     const int64_t c_extent = (((int64_t)M - 1) * ldc + N) * 2;
     p.c_bytes = (unsigned)(c_extent < (1ll << 31) ? c_extent : 0);
     const int nk = (K + BK - 1) / BK;
-    // tile family: 256x256 (8 waves, 1 workgroup/CU) wherever N allows it; 256x128 (4 waves, 2 workgroups/CU,
-    // one hides the other's prologue/epilogue) only for very short K or narrow N -- measured on MI355X the
-    // 256x256 ping-pong kernel wins from K = 512 up; 128x128 for small / ragged outputs
-    bool large = M >= 256 && N >= 128 && ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && (int64_t)M * N * K >= (1ll << 33))) &&
-                 (N % 8 == 0) && (ldc % 8 == 0) && (out_dtype == FCMF_BF16 || epilogue == FCMF_EPI_NONE) &&
-                 epilogue != FCMF_EPI_TANH && epilogue != FCMF_EPI_DTANH && (out_dtype == FCMF_F32 || c_extent < (1ll << 31));
-    int wn = (N >= 256 && nk >= 12) ? 4 : 2;
+    // 256x256 persistent ping-pong kernel for the big problems; 128x128 for small / ragged / narrow outputs,
+    // f32 outputs with an activation epilogue and tanh epilogues (poolers)
+    const bool tile_ok = (N % 8 == 0) && (ldc % 8 == 0) && (out_dtype == FCMF_BF16 || epilogue == FCMF_EPI_NONE) &&
+                         epilogue != FCMF_EPI_TANH && epilogue != FCMF_EPI_DTANH &&
+                         (out_dtype == FCMF_F32 || c_extent < (1ll << 31));
+    bool large = tile_ok && M >= 256 && N >= 256 &&
+                 ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && (int64_t)M * N * K >= (1ll << 33)));
     if (g_force_tile == 128) large = false;
-    if (g_force_tile == 256 || g_force_tile == 257) { large = (N % 8 == 0) && (ldc % 8 == 0) && (out_dtype == FCMF_BF16 || epilogue == FCMF_EPI_NONE) &&
-              epilogue != FCMF_EPI_TANH && epilogue != FCMF_EPI_DTANH && (out_dtype == FCMF_F32 || c_extent < (1ll << 31)); wn = g_force_tile == 256 ? 4 : 2; }
+    if (g_force_tile == 256) large = tile_ok;
     if (large) {
-      const int bn = wn * 64, slots = wn == 4 ? g_num_cus : 2 * g_num_cus;
-      const int tiles_l = ((M + GB - 1) / GB) * ((N + bn - 1) / bn);
+      const int slots = g_num_cus;
+      const int tiles_l = ((M + GB - 1) / GB) * ((N + GB - 1) / GB);
       int ksplit = 1;
       if (accumulate && epilogue == FCMF_EPI_NONE && tiles_l < slots) {
         ksplit = slots / tiles_l;
@@ -1010,17 +1009,10 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       p.tiles = tiles_l;
       p.total_items = tiles_l * p.ksplit;
       dim3 grid(p.total_items < slots ? p.total_items : slots);
-      const int v = (wn == 4 ? 0 : 4) + (trans_a ? 2 : 0) + (trans_b ? 1 : 0);
-      switch (v) {
-        case 0: return launch_bf16_tile<false, false, 4, 4>(p, out_dtype, grid, st);
-        case 1: return launch_bf16_tile<false, true, 4, 4>(p, out_dtype, grid, st);
-        case 2: return launch_bf16_tile<true, false, 4, 4>(p, out_dtype, grid, st);
-        case 3: return launch_bf16_tile<true, true, 4, 4>(p, out_dtype, grid, st);
-        case 4: return launch_bf16_tile<false, false, 2, 3>(p, out_dtype, grid, st);
-        case 5: return launch_bf16_tile<false, true, 2, 3>(p, out_dtype, grid, st);
-        case 6: return launch_bf16_tile<true, false, 2, 3>(p, out_dtype, grid, st);
-        default: return launch_bf16_tile<true, true, 2, 3>(p, out_dtype, grid, st);
-      }
+      if (!trans_a && !trans_b) return launch_bf16_tile<false, false>(p, out_dtype, grid, st);
+      if (!trans_a && trans_b) return launch_bf16_tile<false, true>(p, out_dtype, grid, st);
+      if (trans_a && !trans_b) return launch_bf16_tile<true, false>(p, out_dtype, grid, st);
+      return launch_bf16_tile<true, true>(p, out_dtype, grid, st);
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int ksplit = 1;

@@ -43,11 +43,11 @@ def test_gemm_layouts(dev, dtype, ta, tb, M, N, K):
     assert rel_err(C, ref) < TOL[dtype], (ta, tb, M, N, K)
 
 
-@pytest.mark.parametrize("tile", [128, 256, 257])
+@pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(700, 520, 96), (256, 256, 32), (1000, 776, 224)])
 def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
-    """all MFMA tile kernels (128x128, 256x256 ping-pong, 256x128) on ragged M/N edges and odd k-tile counts"""
+    """both MFMA tile kernels (128x128, persistent 256x256 ping-pong) on ragged M/N edges and odd k-tile counts"""
     ops, H = _ops()
     A = _rand((K, M) if ta else (M, K), dev, torch.bfloat16, seed=1)
     B = _rand((K, N) if tb else (N, K), dev, torch.bfloat16, seed=2)
@@ -64,6 +64,42 @@ def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
     Bf = B.float().cpu() if tb else B.float().cpu().t()
     assert rel_err(C, Af @ Bf + bias.cpu()) < 2e-2
     assert rel_err(Cf, Af @ Bf + 0.5) < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,nk_note", [(700, 520, 96, "3 k-tiles"), (4400, 4104, 64, "306 tiles: two rounds of work items per CU"),
+                                           (300, 264, 32, "1 k-tile"), (1100, 776, 160, "5 k-tiles")])
+def test_gemm_tile256_epilogues(dev, M, N, K, nk_note):
+    """persistent 256x256 kernel, bf16 outputs: every fused epilogue kind (bias / GELU + aux / gelu' / residual
+    add / column sums) on ragged edges, with more work items than workgroups (ring position and next-tile
+    prefetch carried across items) and with 1..5 k-tiles (shorter than the 4-stage ring)"""
+    ops, H = _ops()
+    A, B = _rand((M, K), dev, torch.bfloat16, seed=1), _rand((N, K), dev, torch.bfloat16, 0.2, seed=2)
+    bias = _rand((N,), dev, seed=3)
+    Af, Bf = A.float().cpu(), B.float().cpu()
+    pre = Af @ Bf.t() + bias.cpu()
+    H.lib().fcmf_gemm_force_tile(256)
+    try:
+        C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        aux = torch.empty_like(C)
+        ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, aux=aux, epi=H.EPI_GELU)
+        assert rel_err(aux, pre) < 2e-2
+        assert rel_err(C, torch.nn.functional.gelu(pre)) < 2e-2
+        C2 = torch.empty_like(C)
+        ops.gemm(A, B, C2, M, N, K, K, K, N, False, False, bias=bias, epi=H.EPI_GELU)      # no aux: single pass
+        assert torch.equal(C2, C)
+        u = _rand((M, N), dev, torch.bfloat16, 1.5, seed=5)
+        uf = u.float().cpu()
+        cs = torch.zeros(N, dtype=torch.float32, device=dev)
+        ops.gemm(A, B, C, M, N, K, K, K, N, False, False, aux=u, epi=H.EPI_DGELU, colsum=cs)
+        phi = 0.5 * (1 + torch.erf(uf / 2 ** 0.5))
+        dg = phi + uf * torch.exp(-0.5 * uf * uf) / (2 * 3.141592653589793) ** 0.5
+        ref = (Af @ Bf.t()) * dg
+        assert rel_err(C, ref) < 2e-2
+        assert rel_err(cs, C.float().cpu().sum(0)) < 2e-3          # sums of the values as stored
+        ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, aux=u, epi=H.EPI_ADD)
+        assert rel_err(C, pre + uf) < 2e-2
+    finally:
+        H.lib().fcmf_gemm_force_tile(0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <dlfcn.h>
 #include "fcmf_hip.h"
 
 struct Shape { const char* name; int M, N, K, ta, tb, epi, acc, out_f32; };
@@ -71,6 +72,25 @@ int main(int argc, char** argv) {
     ms /= reps;
     double tf = 2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12;
     printf("%-40s rc=%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 2500)\n", sh.name, rc, ms, tf, tf / 25.0);
+    // diagnostic library (make timing; LD_LIBRARY_PATH=tools/bin/timing): per-phase stamps of workgroup 0
+    typedef void (*tb_fn)(void*);
+    static tb_fn set_buf = (tb_fn)dlsym(RTLD_DEFAULT, "fcmf_gemm_timing_buffer");
+    if (set_buf) {
+      static unsigned long long* dbuf = nullptr;
+      if (!dbuf) hipMalloc(&dbuf, 16 * 8 * 8);
+      hipMemset(dbuf, 0, 16 * 8 * 8);
+      set_buf(dbuf);
+      run();
+      hipDeviceSynchronize();
+      set_buf(nullptr);
+      unsigned long long h[128];
+      hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+      printf("    item: fill  loop(8kt..end)  ->barrier  finish  stores | total   [us, 100 MHz stamps, workgroup 0 wave 0]\n");
+      for (int it = 0; it < 10 && h[it * 8 + 5]; ++it) {
+        auto d = [&](int a, int b2) { return (double)(long long)(h[it * 8 + b2] - h[it * 8 + a]) * 0.01; };
+        printf("    %4d: %5.2f %5.2f+%5.2f %5.2f %5.2f %5.2f | %6.2f\n", it, d(0, 1), d(1, 6), d(6, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 5));
+      }
+    }
   }
   return 0;
 }
