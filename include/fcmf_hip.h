@@ -62,8 +62,8 @@ int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* au
               int trans_a, int trans_b, int in_dtype, int out_dtype,
               int epilogue, int accumulate, void* stream);
 
-/* tuning hook for benchmarks/tests: 0 = built-in heuristic; 128 = 128x128 kernel, 256 = persistent 256x256
- * kernel wherever its preconditions hold */
+/* tuning hook for benchmarks/tests: 0 = built-in heuristic; 128 = 128x128 kernel, 256 / 192 = persistent
+ * 256x256 / 192x256 kernel wherever its preconditions hold */
 void fcmf_gemm_force_tile(int tile);
 
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X dtype = dtype, out float32. */

@@ -345,6 +345,8 @@ __device__ __forceinline__ unsigned dma_voffset_t(int piece, int lane, int64_t l
   }
 }
 
+template <int V> struct IntTag { static constexpr int value = V; };
+
 // 8 consecutive outputs of one row <-> four packed-f32 pairs
 __device__ __forceinline__ void load8f(const float* q, f32x2 (&v)[4]) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(q), b = *reinterpret_cast<const f32x4*>(q + 4);
@@ -355,14 +357,23 @@ __device__ __forceinline__ void store8f(float* q, const f32x2 (&v)[4]) {
   *reinterpret_cast<f32x4*>(q + 4) = f32x4{v[2][0], v[2][1], v[3][0], v[3][1]};
 }
 
-template <bool A_TR, bool B_TR, typename TC, int EPI>
+// MI = 16-row fragments per wave along M: 8 -> 256x256 block tile, 6 -> 192x256 (row-major A only).  The
+// 192-row variant exists for tile-count quantisation: M = 49152, N = 768 gives 576 tiles of 256 rows (2.25
+// rounds on 256 CUs, the last one a quarter full) but 768 tiles of 192 rows = exactly 3 rounds of 3/4 the work.
+template <bool A_TR, bool B_TR, typename TC, int EPI, int MI>
 __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
+  static_assert(MI == 8 || (MI == 6 && !A_TR && sizeof(TC) == 2), "192-row tiles: row-major A, bf16 output");
   constexpr int NW = 8;
-  constexpr int A_PIECES = 2, B_PIECES = 2;    // 1 KiB DMA pieces per wave per operand tile
+  constexpr int TM = 32 * MI;                  // block tile rows
+  constexpr int WM = 16 * MI;                  // rows per wave
+  constexpr int A_PIECES = 2, B_PIECES = 2;    // 1 KiB DMA pieces per wave per operand tile (A: see na_pieces)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;     // rows wm*128, cols wn*64
+  const int wm = wave >> 2, wn = wave & 3;     // rows wm*WM, cols wn*64
+  // the 12 KiB A tile of the 192-row variant is 12 pieces: two for waves 0-3, one (pieces 8..11) for waves 4-7
+  const int na_pieces = (MI == 8 || wave < 4) ? 2 : 1;
+  const int a_piece0 = (MI == 8 || wave < 4) ? wave * 2 : 4 + wave;
 
   // XCD-aware order inside a round: the workgroups of one XCD (blockIdx % 8) take consecutive logical
   // items, and consecutive items share the A row-panel (all N tiles of one M tile) -> L2 hits.
@@ -385,9 +396,9 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   const int row_base = rowl * 64 + ((g4 ^ swz_row(rowl)) << 4);
   const int trk = tr_key(8 * g4 + q4);
   const int tr_col = ((p4 >> 1) << 4) + ((p4 & 1) << 3);
-  const int a_lane = A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * 128 * 64;
+  const int a_lane = A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * WM * 64;
   const int b_lane = A_TILE_BYTES + (B_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wn * 64 * 64);
-  auto frag_a = [&](const char* st, int f) -> bf16x8 {     // f = 0..7: 16-row fragment of this wave's 128 rows
+  auto frag_a = [&](const char* st, int f) -> bf16x8 {     // f = 0..MI-1: 16-row fragment of this wave's rows
     if (!A_TR) return *reinterpret_cast<const bf16x8*>(st + a_lane + f * 1024);
     const char* q = st + a_lane + (((wm * 8 + f) ^ trk) << 5);
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
@@ -411,7 +422,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     const int zsplit = item / p.tiles, tile = item - zsplit * p.tiles;
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int kb = zsplit * p.ktiles_per_split;
-    return Item{tile_m * GB, tile_n * GB, kb, min(nk_total, kb + p.ktiles_per_split) - kb, zsplit};
+    return Item{tile_m * TM, tile_n * GB, kb, min(nk_total, kb + p.ktiles_per_split) - kb, zsplit};
   };
   // ring: k-tile t of the current item lives in stage (base + t) % 4; `base` runs on across items
   int base = 0;
@@ -421,7 +432,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   auto sources = [&](const Item& w) -> Src {
     Src r;
 #pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR>(wave * A_PIECES + j, lane, p.lda, w.i0, p.M);
+    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR>(a_piece0 + j, lane, p.lda, w.i0, p.M);
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
     return r;
@@ -432,7 +443,8 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
-      char* d = st + (wave * A_PIECES + j) * 1024;
+      if (MI != 8 && j >= na_pieces) break;
+      char* d = st + (a_piece0 + j) * 1024;
       if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j] + ka, 0, 0, 0);
       else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j], ka, 0, 0);
     }
@@ -462,32 +474,33 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   // after barrier t.  Own DMAs of tile t have landed once at most the two younger tiles (4 DMAs each) are
   // outstanding: loads retire in order, and stores of the previous epilogue that are still in flight only
   // make the wait longer.
-  auto wait_landed = [&](int t) {
+  auto wait_landed = [&](int t, auto per_tile) {
+    constexpr int PT = decltype(per_tile)::value;   // DMAs per k-tile of this wave: 4, or 3 for waves 4-7 of the 192-row tile
     const int younger = nkt - 1 - t;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (younger >= 2) { if (PT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else if (younger == 1) { if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto issue_after_barrier = [&](int t) {
     if (t + 3 < nkt) issue(w, src, t + 3, base + t + 3);
   };
 
-  f32x4 acc[4][8];  // [j frag][i frag]
+  f32x4 acc[4][MI];  // [j frag][i frag]
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa[8], fb[4];
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[MI], fb[4];
   auto load_frags = [&](int t) {
     const char* st = stage_at(base + t);
 #pragma unroll
     for (int f = 0; f < 4; ++f) fb[f] = frag_b(st, f);
 #pragma unroll
-    for (int f = 0; f < 8; ++f) fa[f] = frag_a(st, f);
+    for (int f = 0; f < MI; ++f) fa[f] = frag_a(st, f);
   };
   auto mma = [&]() {
 #pragma unroll
-    for (int fi = 0; fi < 8; ++fi)
+    for (int fi = 0; fi < MI; ++fi)
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj)
         // D rows <- B operand (j), D cols <- A operand (i)
@@ -506,7 +519,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   const bool group_b = wave >= 4;              // wave is an SGPR: a uniform branch
   if (!group_b) {
     for (int t = 0; t < nkt; ++t) {
-      wait_landed(t);
+      wait_landed(t, IntTag<4>{});
       __builtin_amdgcn_s_barrier();            // tile t visible; the stage of tile t-1 is no longer read
 #ifdef FCMF_GEMM_TIMING
       if (t == 0) FCMF_STAMP(1);
@@ -518,7 +531,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     }
   } else {
     for (int t = 0; t < nkt; ++t) {
-      wait_landed(t);
+      wait_landed(t, IntTag<(MI == 8 ? 4 : 3)>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads of tile t-1 have left LDS
       __builtin_amdgcn_s_barrier();
       if (t > 0) mma();                                     // tile t-1
@@ -542,7 +555,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     asm volatile("" : "+v"(lane_e));            //  hoisted above the main loop, where every VGPR is spoken for)
     const int er = lane_e & 15, eg = lane_e >> 4;
     const unsigned ldc2 = (unsigned)p.ldc * 2u;
-    const unsigned tile_off = (unsigned)(i0 + wm * 128) * ldc2 + (unsigned)(j0 + wn * 64) * 2u;   // wave's sub-tile
+    const unsigned tile_off = (unsigned)(i0 + wm * WM) * ldc2 + (unsigned)(j0 + wn * 64) * 2u;   // wave's sub-tile
     constexpr bool HAS_AUX = (EPI == FCMF_EPI_DGELU || EPI == FCMF_EPI_ADD);
     // transposition slice: fragment-layout accesses are 8 B per lane, row-layout accesses 16 B per lane (whole
     // 128-B row pieces, 8 rows per instruction); LDS executes a wave's accesses in order
@@ -594,7 +607,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         const int gj = j0 + wn * 64 + eg * 4 + fj * 16;
         const f32x4 bq = gj < p.N ? *reinterpret_cast<const f32x4*>(p.bias + gj) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int fi = 0; fi < 8; ++fi) acc[fj][fi] = acc[fj][fi] + bq;
+        for (int fi = 0; fi < MI; ++fi) acc[fj][fi] = acc[fj][fi] + bq;
       }
     }
     auto pack = [&](f32x4 v) __attribute__((always_inline)) -> u32x2 {
@@ -614,7 +627,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       for (int it = 0; it < 4; ++it) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x[it]), rD, sbase + (unsigned)(rnd * 32 + it * 8) * ldc2, 0, 0);
         if (sums) {
-          const int gi = i0 + wm * 128 + rnd * 32 + it * 8 + rrow;
+          const int gi = i0 + wm * WM + rnd * 32 + it * 8 + rrow;
           if (gi < p.M) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) csum[e] += (float)x[it][e];
@@ -625,10 +638,10 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     if constexpr (HAS_AUX) {
       // round by round (32 rows): aux rows -> slice -> fragment layout, math, results -> slice -> rows -> C
 #pragma unroll
-      for (int rnd = 0; rnd < 4; ++rnd) {
+      for (int rnd = 0; rnd < MI / 2; ++rnd) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(row_addr(it)) = ax[rnd & 1][it];
-        if (rnd + 2 < 4) load_aux(rnd + 2);
+        if (rnd + 2 < MI / 2) load_aux(rnd + 2);
         u32x2 o[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -653,9 +666,9 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       const bool two_pass = (EPI == FCMF_EPI_GELU) && p.aux != nullptr;
       // accumulators -> finished bf16 values (straight-line code; the accumulator registers die as it goes).
       // o1 = the C values, o0 = the pre-activations that FCMF_EPI_GELU also writes to aux.
-      u32x2 o0[EPI == FCMF_EPI_GELU ? 32 : 1], o1[32];
+      u32x2 o0[EPI == FCMF_EPI_GELU ? 4 * MI : 1], o1[4 * MI];
 #pragma unroll
-      for (int fi = 0; fi < 8; ++fi) {
+      for (int fi = 0; fi < MI; ++fi) {
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) {
           f32x4 v = acc[fj][fi];
@@ -670,7 +683,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       FCMF_STAMP(4);
       auto write_out = [&](const auto& o, const __amdgpu_buffer_rsrc_t& rD, bool sums) __attribute__((always_inline)) {
 #pragma unroll
-        for (int rnd = 0; rnd < 4; ++rnd) {
+        for (int rnd = 0; rnd < MI / 2; ++rnd) {
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -693,7 +706,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice reads have returned before the wave moves on
-  } else {
+  } else if constexpr (MI == 8) {
     // ---- f32 epilogue (weight gradients: accumulate / split-K; epilogue kind is always NONE here):
     // accumulators -> LDS (f32, one 128-row half at a time, the whole ring) -> row-wise output with
     // whole-row stores or 256-byte float atomics for split-K
@@ -930,25 +943,37 @@ static int launch_bf16(const GemmParams& p, int out_dtype, dim3 grid, hipStream_
 // inside a kernel template -- it would silently drop the host-side kernel handle)
 template <bool A_TR, bool B_TR, typename TC, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmParams p) {
-  gemm_bf16_tile256_body<A_TR, B_TR, TC, EPI>(p);
+  gemm_bf16_tile256_body<A_TR, B_TR, TC, EPI, 8>(p);
+}
+template <bool B_TR, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tile192_kernel(GemmParams p) {
+  gemm_bf16_tile256_body<false, B_TR, bf16_t, EPI, 6>(p);
 }
 
 template <bool A_TR, bool B_TR, typename TC, int EPI>
-static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, hipStream_t st) {
+static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, hipStream_t st, int tm) {
   const size_t smem = (size_t)TNST * TSTAGE_BYTES + 8 * 4096;   // ring + per-wave transposition slices = 160 KiB
+  if constexpr (!A_TR && sizeof(TC) == 2) {
+    if (tm == 192) {
+      auto k = gemm_bf16_tile192_kernel<B_TR, EPI>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+      return;
+    }
+  }
   auto k = gemm_bf16_tile256_kernel<A_TR, B_TR, TC, EPI>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
 }
 
 template <bool A_TR, bool B_TR>
-static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st) {
-  if (out_dtype == FCMF_F32) launch_bf16_tile_typed<A_TR, B_TR, float, FCMF_EPI_NONE>(p, grid, st);
+static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st, int tm) {
+  if (out_dtype == FCMF_F32) launch_bf16_tile_typed<A_TR, B_TR, float, FCMF_EPI_NONE>(p, grid, st, 256);
   else switch (p.epilogue) {
-    case FCMF_EPI_NONE: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_NONE>(p, grid, st); break;
-    case FCMF_EPI_GELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_GELU>(p, grid, st); break;
-    case FCMF_EPI_DGELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_DGELU>(p, grid, st); break;
-    default: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_ADD>(p, grid, st); break;
+    case FCMF_EPI_NONE: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_NONE>(p, grid, st, tm); break;
+    case FCMF_EPI_GELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_GELU>(p, grid, st, tm); break;
+    case FCMF_EPI_DGELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_DGELU>(p, grid, st, tm); break;
+    default: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_ADD>(p, grid, st, tm); break;
   }
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
@@ -994,10 +1019,21 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     bool large = tile_ok && M >= 256 && N >= 256 &&
                  ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && (int64_t)M * N * K >= (1ll << 33)));
     if (g_force_tile == 128) large = false;
-    if (g_force_tile == 256) large = tile_ok;
+    if (g_force_tile == 256 || g_force_tile == 192) large = tile_ok;
     if (large) {
       const int slots = g_num_cus;
-      const int tiles_l = ((M + GB - 1) / GB) * ((N + GB - 1) / GB);
+      // block tile rows: 256, or 192 where that removes a nearly empty last round (cost model: rounds x
+      // (k-loop time scaled by the tile rows + a fixed per-tile cost of ~8 k-tiles))
+      int tm = 256;
+      if (!trans_a && out_dtype == FCMF_BF16 && !accumulate) {
+        auto cost = [&](int rows) {
+          const int64_t t = (int64_t)((M + rows - 1) / rows) * ((N + GB - 1) / GB);
+          return (double)((t + slots - 1) / slots) * (nk * (rows / 256.0) + 8.0);
+        };
+        if (cost(192) < 0.97 * cost(256)) tm = 192;
+      }
+      if (g_force_tile == 192 && !trans_a && out_dtype == FCMF_BF16 && !accumulate) tm = 192;
+      const int tiles_l = ((M + tm - 1) / tm) * ((N + GB - 1) / GB);
       int ksplit = 1;
       if (accumulate && epilogue == FCMF_EPI_NONE && tiles_l < slots) {
         ksplit = slots / tiles_l;
@@ -1009,10 +1045,10 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       p.tiles = tiles_l;
       p.total_items = tiles_l * p.ksplit;
       dim3 grid(p.total_items < slots ? p.total_items : slots);
-      if (!trans_a && !trans_b) return launch_bf16_tile<false, false>(p, out_dtype, grid, st);
-      if (!trans_a && trans_b) return launch_bf16_tile<false, true>(p, out_dtype, grid, st);
-      if (trans_a && !trans_b) return launch_bf16_tile<true, false>(p, out_dtype, grid, st);
-      return launch_bf16_tile<true, true>(p, out_dtype, grid, st);
+      if (!trans_a && !trans_b) return launch_bf16_tile<false, false>(p, out_dtype, grid, st, tm);
+      if (!trans_a && trans_b) return launch_bf16_tile<false, true>(p, out_dtype, grid, st, tm);
+      if (trans_a && !trans_b) return launch_bf16_tile<true, false>(p, out_dtype, grid, st, tm);
+      return launch_bf16_tile<true, true>(p, out_dtype, grid, st, tm);
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int ksplit = 1;

@@ -9,6 +9,8 @@ views of, and all weight-gradient buffers of a layer come from a single zero fil
 """
 import math
 
+import os
+
 import torch
 
 from . import _hip as H
@@ -75,7 +77,7 @@ def _fused_weight(ws, dtype):
 # the layer's backward reads it, so it runs on a second stream: its persistent workgroups fill the CUs
 # that the tail rounds of the dX GEMMs (and the memory-bound LayerNorm / attention kernels) leave idle.
 # The main stream re-joins at the end of the layer's backward, before autograd sees the gradients.
-USE_SIDE_STREAM = True
+USE_SIDE_STREAM = os.environ.get("FCMF_SIDE_STREAM", "1") != "0"   # FCMF_SIDE_STREAM=0: everything on one stream
 _side = {}
 
 

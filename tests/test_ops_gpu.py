@@ -43,11 +43,11 @@ def test_gemm_layouts(dev, dtype, ta, tb, M, N, K):
     assert rel_err(C, ref) < TOL[dtype], (ta, tb, M, N, K)
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 192])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(700, 520, 96), (256, 256, 32), (1000, 776, 224)])
 def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
-    """both MFMA tile kernels (128x128, persistent 256x256 ping-pong) on ragged M/N edges and odd k-tile counts"""
+    """all MFMA tile kernels (128x128, persistent 256x256 / 192x256 ping-pong) on ragged M/N edges and odd k-tile counts"""
     ops, H = _ops()
     A = _rand((K, M) if ta else (M, K), dev, torch.bfloat16, seed=1)
     B = _rand((K, N) if tb else (N, K), dev, torch.bfloat16, seed=2)
@@ -68,8 +68,9 @@ def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
 
 @pytest.mark.parametrize("M,N,K,nk_note", [(700, 520, 96, "3 k-tiles"), (4400, 4104, 64, "306 tiles: two rounds of work items per CU"),
                                            (300, 264, 32, "1 k-tile"), (1100, 776, 160, "5 k-tiles")])
-def test_gemm_tile256_epilogues(dev, M, N, K, nk_note):
-    """persistent 256x256 kernel, bf16 outputs: every fused epilogue kind (bias / GELU + aux / gelu' / residual
+@pytest.mark.parametrize("tile", [256, 192])
+def test_gemm_tile256_epilogues(dev, tile, M, N, K, nk_note):
+    """persistent 256x256 / 192x256 kernels, bf16 outputs: every fused epilogue kind (bias / GELU + aux / gelu' / residual
     add / column sums) on ragged edges, with more work items than workgroups (ring position and next-tile
     prefetch carried across items) and with 1..5 k-tiles (shorter than the 4-stage ring)"""
     ops, H = _ops()
@@ -77,7 +78,7 @@ def test_gemm_tile256_epilogues(dev, M, N, K, nk_note):
     bias = _rand((N,), dev, seed=3)
     Af, Bf = A.float().cpu(), B.float().cpu()
     pre = Af @ Bf.t() + bias.cpu()
-    H.lib().fcmf_gemm_force_tile(256)
+    H.lib().fcmf_gemm_force_tile(tile)
     try:
         C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         aux = torch.empty_like(C)
