@@ -1,9 +1,10 @@
 // MFMA attention for the text-encoder layers: bf16, head dim 64, Tk <= 128 keys per (sequence, head).
 //   forward : one workgroup per (sequence, head, 128-query tile); K and V tiles staged once in LDS;
 //             each of the 4 waves owns 32 query rows: S^T = K Q^T on v_mfma_f32_16x16x32_bf16 with the
-//             key index in the accumulator registers (row max / sum = 32 in-lane values + 2 shuffles),
-//             P round-trips through a per-wave LDS tile, O^T = V^T P^T with V consumed through
-//             ds_read_b64_tr_b16 straight from its row-major image.
+//             key index in the accumulator registers (row max / sum = 32 in-lane values + 2 shuffles);
+//             the normalised, dropped-out P^T accumulators ARE the operand of O^T = V^T P^T (keys taken in
+//             the order the accumulator registers hold them; V is consumed through ds_read_b64_tr_b16 in
+//             that same order straight from its row-major image): 32 KiB of LDS, four workgroups per CU.
 //   backward: one workgroup per (sequence, head), Tq <= 128: P is recomputed from the saved logsumexp;
 //             phase 1 (wave = 32 query rows) builds Pdrop^T and dS^T [key][query] in LDS, phase 2
 //             (wave = 32 keys / 32 queries) forms dV, dK, dQ as 96 MFMAs per wave, no atomics.
@@ -24,6 +25,11 @@ __device__ __forceinline__ int off128(int r, int ch) { return r * 256 + ((ch ^ k
 // per-wave P tile of the forward [32][128 bf16]: chunk XOR (row & 15)
 __device__ __forceinline__ int offp(int r, int ch) { return r * 256 + ((ch ^ (r & 15)) << 4); }
 
+// forward-only V image: 32-B pair index XOR ((r>>1)&3), conflict free for the KEY-PERMUTED transposed reads
+// (k-slot j of k-step s = key 32s + 4*(lane>>4) + (j&3) + 16*(j>>2): the order in which the S^T accumulator
+// registers of two adjacent key fragments line up as an MFMA operand, so P never leaves the registers)
+__device__ __forceinline__ int off64p(int r, int c8) { return r * 128 + ((((c8 >> 1) ^ ((r >> 1) & 3))) << 5) + ((c8 & 1) << 4); }
+
 typedef bf16x4 __attribute__((address_space(3))) * lds_v4_t;
 
 // stage a [rows<=128][64] bf16 tile (row stride ld elements) into the off64 image, zero-filling
@@ -35,6 +41,25 @@ __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* __restrict__
     if (r < rows) v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + c8 * 8);
     *reinterpret_cast<uint4*>(lds + off64(r, c8)) = v;
   }
+}
+__device__ __forceinline__ void stage_tile_p(char* lds, const bf16_t* __restrict__ src, int64_t ld, int rows, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, r = c >> 3, c8 = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < rows) v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + c8 * 8);
+    *reinterpret_cast<uint4*>(lds + off64p(r, c8)) = v;
+  }
+}
+// A[row = tile column c0 + (lane&15)][k = keys in the permuted order above] from the off64p image
+__device__ __forceinline__ bf16x8 frag_tr64p(const char* lds, int c0, int s, int lane) {
+  const int g4 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p = i16 & 3;
+  const int r = 32 * s + 4 * g4 + q4, c8 = (c0 >> 3) + (p >> 1);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(lds + off64p(r, c8) + (p & 1) * 8));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(lds + off64p(r + 16, c8) + (p & 1) * 8));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3]; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
 }
 // MFMA operand (rows x0..x0+15, k-step s over the 64 columns) by row read
 __device__ __forceinline__ bf16x8 frag_row64(const char* lds, int x0, int s, int lane) {
@@ -81,16 +106,15 @@ struct AttnMfmaParams {
 };
 
 // =========================================================================================
-__global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnMfmaParams P) {
+__global__ __launch_bounds__(256, 4) void attn_mfma_fwd_kernel(AttnMfmaParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  char* Pw = smem + 2 * TILE_B + w * (32 * 256);
   const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
   const int q0 = blockIdx.y * AT + w * 32;
   stage_tile(Ks, P.k + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
-  stage_tile(Vs, P.v + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
+  stage_tile_p(Vs, P.v + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
 
   // Q fragments straight from global memory in operand layout (16 B per lane)
   bf16x8 qf[2][2];
@@ -153,20 +177,12 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnMfmaParams P)
     if (q < P.Tq && (lane >> 4) == 0 && P.lse) P.lse[((int64_t)g * P.heads + h) * P.Tq + q] = m + __logf(sum);
 #pragma unroll
     for (int kf = 0; kf < 8; ++kf) {
-      f32x4 pv;
+      float dm[4] = {1.f, 1.f, 1.f, 1.f};
+      if (P.p > 0.f) dropout_mult4(P.seed, (((uint64_t)g * P.heads + h) * P.Tq + q) * P.Tk + 16 * kf + 4 * (lane >> 4), P.p, inv_keep, dm);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = sc[kf][f][r] * inv;
-        if (P.p > 0.f) {
-          const int key = 16 * kf + 4 * (lane >> 4) + r;
-          x *= dropout_mult(P.seed, (((uint64_t)g * P.heads + h) * P.Tq + q) * P.Tk + key, P.p, inv_keep);
-        }
-        pv[r] = x;
-      }
-      store4(reinterpret_cast<bf16_t*>(Pw + offp(16 * f + (lane & 15), 2 * kf + (lane >> 5)) + ((lane >> 4) & 1) * 8), pv);
+      for (int r = 0; r < 4; ++r) sc[kf][f][r] = sc[kf][f][r] * inv * dm[r];
     }
   }
-  __syncthreads();
   // O^T[d][q] = sum_key V[key][d] P[q][key]
   f32x4 oc[4][2];
 #pragma unroll
@@ -175,13 +191,15 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnMfmaParams P)
     for (int f = 0; f < 2; ++f) oc[df][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
+    // P^T operand of k-step s straight from the accumulators of key fragments 2s and 2s+1
     bf16x8 pb[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
-      pb[f] = *reinterpret_cast<const bf16x8*>(Pw + offp(16 * f + (lane & 15), 4 * s + (lane >> 4)));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pb[f][r] = (bf16_t)sc[2 * s][f][r]; pb[f][4 + r] = (bf16_t)sc[2 * s + 1][f][r]; }
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
-      const bf16x8 va = frag_tr64(Vs, 16 * df, s, lane);
+      const bf16x8 va = frag_tr64p(Vs, 16 * df, s, lane);
 #pragma unroll
       for (int f = 0; f < 2; ++f) oc[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[f], oc[df][f], 0, 0, 0);
     }
@@ -358,7 +376,7 @@ extern "C" int fcmf_attn_mfma_fwd(const void* q, const void* k, const void* v, c
   P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.mask = mask; P.out = (bf16_t*)out; P.lse = lse;
   P.G = G; P.heads = heads; P.Tq = Tq; P.Tk = Tk; P.ldq = ldq; P.ldk = ldk; P.ldo = ldo;
   P.scale = scale; P.p = dropout_p; P.seed = seed;
-  const int smem = 2 * TILE_B + 4 * 32 * 256;
+  const int smem = 2 * TILE_B;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
   hipLaunchKernelGGL(attn_mfma_fwd_kernel, dim3(G * heads, (Tq + AT - 1) / AT), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);

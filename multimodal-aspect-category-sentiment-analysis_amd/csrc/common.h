@@ -60,19 +60,41 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // ---- counter-based dropout RNG --------------------------------------------------------------
-// Stateless hash of (seed, element index): forward and backward regenerate the same mask
-// without storing it.  murmur3-style finaliser over a 64-bit counter folded with the seed.
-__device__ __forceinline__ uint32_t fcmf_hash(uint64_t seed, uint64_t idx) {
-  uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return (uint32_t)x;
+// Stateless hash of (seed, element index): forward and backward regenerate the same mask without storing
+// it.  One 32-bit hash (the "lowbias32" integer finaliser: two 32-bit multiplies -- integer multiplies are
+// quarter rate on CDNA, so they are what a mask costs) decides TWO consecutive elements, 16 bits each: an
+// element is dropped when its 16 bits fall below p * 65536 (p is honoured to 1.5e-5).
+__device__ __forceinline__ uint32_t fcmf_hash32(uint64_t seed, uint64_t pair) {
+  const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
+  uint32_t x = lo ^ s0 ^ ((hi << 7) | (hi >> 25));
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= s1;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
+__device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 // returns the multiplier applied to the element: 0 (dropped) or 1/(1-p) (kept)
 __device__ __forceinline__ float dropout_mult(uint64_t seed, uint64_t idx, float p, float inv_keep) {
-  float u = (float)(fcmf_hash(seed, idx) >> 8) * (1.0f / 16777216.0f);
-  return u >= p ? inv_keep : 0.0f;
+  const uint32_t h = fcmf_hash32(seed, idx >> 1);
+  const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+  return bits >= dropout_threshold(p) ? inv_keep : 0.0f;
+}
+// multipliers of the 4 consecutive elements base .. base+3 (same values as four dropout_mult calls):
+// two hashes when base is even, three otherwise
+__device__ __forceinline__ void dropout_mult4(uint64_t seed, uint64_t base, float p, float inv_keep, float (&m)[4]) {
+  const uint32_t thr = dropout_threshold(p);
+  const uint64_t k0 = base >> 1;
+  const uint32_t h0 = fcmf_hash32(seed, k0), h1 = fcmf_hash32(seed, k0 + 1);
+  if ((base & 1) == 0) {
+    m[0] = (h0 & 0xFFFFu) >= thr ? inv_keep : 0.f; m[1] = (h0 >> 16) >= thr ? inv_keep : 0.f;
+    m[2] = (h1 & 0xFFFFu) >= thr ? inv_keep : 0.f; m[3] = (h1 >> 16) >= thr ? inv_keep : 0.f;
+  } else {
+    const uint32_t h2 = fcmf_hash32(seed, k0 + 2);
+    m[0] = (h0 >> 16) >= thr ? inv_keep : 0.f;     m[1] = (h1 & 0xFFFFu) >= thr ? inv_keep : 0.f;
+    m[2] = (h1 >> 16) >= thr ? inv_keep : 0.f;     m[3] = (h2 & 0xFFFFu) >= thr ? inv_keep : 0.f;
+  }
 }
 
 // exact-erf GELU and its derivative (mm_modeling.py:10-15)

@@ -26,8 +26,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
       float4 a = Vec4<T>::load(x + (int64_t)row * H + c);
       if (p > 0.f) {
         const uint64_t base = (uint64_t)row * H + c;
-        a.x *= dropout_mult(seed, base + 0, p, inv_keep); a.y *= dropout_mult(seed, base + 1, p, inv_keep);
-        a.z *= dropout_mult(seed, base + 2, p, inv_keep); a.w *= dropout_mult(seed, base + 3, p, inv_keep);
+        float dm[4];
+        dropout_mult4(seed, base, p, inv_keep, dm);
+        a.x *= dm[0]; a.y *= dm[1]; a.z *= dm[2]; a.w *= dm[3];
       }
       if (res) {
         float4 r = Vec4<T>::load(res + (int64_t)row * res_stride + c);
@@ -117,8 +118,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
         Vec4<T>::store(dz + (int64_t)row * H + c, o);
         if (dx) {
           const uint64_t base = (uint64_t)row * H + c;
-          o.x *= dropout_mult(seed, base + 0, p, inv_keep); o.y *= dropout_mult(seed, base + 1, p, inv_keep);
-          o.z *= dropout_mult(seed, base + 2, p, inv_keep); o.w *= dropout_mult(seed, base + 3, p, inv_keep);
+          float dm[4];
+          dropout_mult4(seed, base, p, inv_keep, dm);
+          o.x *= dm[0]; o.y *= dm[1]; o.z *= dm[2]; o.w *= dm[3];
           Vec4<T>::store(dx + (int64_t)row * H + c, o);
         }
         // column sums of the gradient that flows into the producing Linear = its bias gradient
@@ -264,8 +266,9 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
       o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
       if (p > 0.f) {  // HF applies dropout AFTER the embedding LayerNorm
         const uint64_t base = (uint64_t)row * H + c;
-        o.x *= dropout_mult(seed, base + 0, p, inv_keep); o.y *= dropout_mult(seed, base + 1, p, inv_keep);
-        o.z *= dropout_mult(seed, base + 2, p, inv_keep); o.w *= dropout_mult(seed, base + 3, p, inv_keep);
+        float dm[4];
+        dropout_mult4(seed, base, p, inv_keep, dm);
+        o.x *= dm[0]; o.y *= dm[1]; o.z *= dm[2]; o.w *= dm[3];
       }
       Vec4<T>::store(y + (int64_t)row * H + c, o);
     }

@@ -1,0 +1,15 @@
+import sys, os, importlib
+sys.path.insert(0, os.getcwd())
+import torch
+import bench  # noqa
+pkg = importlib.import_module("fcmf_framework.ops")
+orig = pkg.AttentionFn.forward
+seen = set()
+def fwd(ctx, q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal):
+    key = (tuple(q.shape), None if k1 is None else tuple(k1.shape), None if k2 is None else tuple(k2.shape), mask is not None, bias is not None, heads, group_div, p, causal, str(q.dtype))
+    if key not in seen:
+        seen.add(key); print("ATTN", key, flush=True)
+    return orig(ctx, q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal)
+pkg.AttentionFn.forward = staticmethod(fwd)
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "0"]
+bench.main()
