@@ -5,9 +5,12 @@
 //             the normalised, dropped-out P^T accumulators ARE the operand of O^T = V^T P^T (keys taken in
 //             the order the accumulator registers hold them; V is consumed through ds_read_b64_tr_b16 in
 //             that same order straight from its row-major image): 32 KiB of LDS, four workgroups per CU.
-//   backward: one workgroup per (sequence, head), Tq <= 128: P is recomputed from the saved logsumexp;
-//             phase 1 (wave = 32 query rows) builds Pdrop^T and dS^T [key][query] in LDS, phase 2
-//             (wave = 32 keys / 32 queries) forms dV, dK, dQ as 96 MFMAs per wave, no atomics.
+//   backward: one workgroup per (sequence, head), Tq <= 128: P is recomputed from the saved logsumexp.
+//             The keys go by in chunks of 32: phase 1 (wave = 32 query rows) builds Pdrop^T and dS^T
+//             [key][query] of the chunk in LDS, phase 2 adds the chunk to dQ (wave = 32 queries, accumulators
+//             live across chunks) and finishes dV / dK of the chunk's keys (wave = 16 head-dim columns, the
+//             transposed dO / Q operands stay in registers).  80 KiB of LDS: two workgroups per CU overlap
+//             each other's loads, barriers and stores; no atomics.
 // One LDS image per tile serves both row reads (ds_read_b128) and transposed reads
 // (ds_read_b64_tr_b16); swizzles verified conflict-free with tools/lds_conflicts.py.
 #include "common.h"
@@ -216,15 +219,14 @@ __global__ __launch_bounds__(256, 4) void attn_mfma_fwd_kernel(AttnMfmaParams P)
 }
 
 // =========================================================================================
-__global__ __launch_bounds__(256, 1) void attn_mfma_bwd_kernel(AttnMfmaParams P) {
+__global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(AttnMfmaParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
   char* Ks = smem + TILE_B;
   char* Vs = smem + 2 * TILE_B;
   char* dOs = smem + 3 * TILE_B;
-  char* PdT = smem + 4 * TILE_B;              // [128 keys][128 q] bf16, 32 KiB
-  char* dST = PdT + 2 * TILE_B;               // 32 KiB
-  float* delta = reinterpret_cast<float*>(dST + 2 * TILE_B);  // [128]
+  char* PdT = smem + 4 * TILE_B;              // [32 keys][128 q] bf16 of the current key chunk, 8 KiB
+  char* dST = PdT + TILE_B / 2;               // 8 KiB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
   const int64_t qbase = (int64_t)g * P.Tq, kbase = (int64_t)g * P.Tk;
@@ -232,9 +234,12 @@ __global__ __launch_bounds__(256, 1) void attn_mfma_bwd_kernel(AttnMfmaParams P)
   stage_tile(Ks, P.k + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
   stage_tile(Vs, P.v + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
   stage_tile(dOs, P.dout + qbase * P.ldo + h * AD, P.ldo, P.Tq, tid);
-  {  // delta[q] = sum_d dO[q][d] O[q][d]: two threads per query row
-    const int q = tid >> 1, half = tid & 1;
-    float s = 0.f;
+  // delta[q] = sum_d dO[q][d] O[q][d] for the wave's 32 query rows: two lanes per row, then every lane picks
+  // the values of the rows its accumulator registers hold (no LDS: the 80 KiB are spoken for)
+  float dl4[2][4], lse4[2][4];
+  {
+    const int q = 32 * w + (lane >> 1), half = lane & 1;
+    float sd = 0.f;
     if (q < P.Tq) {
       const bf16_t* a = P.dout + (qbase + q) * P.ldo + h * AD + 32 * half;
       const bf16_t* b = P.o + (qbase + q) * P.ldo + h * AD + 32 * half;
@@ -243,18 +248,27 @@ __global__ __launch_bounds__(256, 1) void attn_mfma_bwd_kernel(AttnMfmaParams P)
         const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + 8 * i);
         const bf16x8 y = *reinterpret_cast<const bf16x8*>(b + 8 * i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)x[j] * (float)y[j];
+        for (int j = 0; j < 8; ++j) sd += (float)x[j] * (float)y[j];
       }
     }
-    s += __shfl_xor(s, 1, 64);
-    if (half == 0) delta[q] = s;
+    sd += __shfl_xor(sd, 1, 64);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * f + 4 * (lane >> 4) + r;          // row inside the wave's 32
+        dl4[f][r] = __shfl(sd, 2 * ql, 64);
+        const int q2 = 32 * w + ql;
+        lse4[f][r] = q2 < P.Tq ? P.lse[((int64_t)g * P.heads + h) * P.Tq + q2] : 0.f;
+      }
   }
   __syncthreads();
 
-  // ---- phase 1: wave w = query rows 32w..32w+31; S and dP with D[q][key] --------------------
   const float inv_keep = P.p > 0.f ? 1.0f / (1.0f - P.p) : 1.0f;
   const float* mrow = P.mask ? P.mask + kbase : nullptr;
-  bf16x8 qa[2][2], da[2][2];
+  // operands that stay in registers: the wave's 32 query rows of Q and dO (phase 1) and the transposed
+  // 16-column slices dO^T / Q^T [d = 16w ..][q] that dV / dK of every key chunk multiply (phase 2)
+  bf16x8 qa[2][2], da[2][2], oT[4], qT[4];
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -262,37 +276,41 @@ __global__ __launch_bounds__(256, 1) void attn_mfma_bwd_kernel(AttnMfmaParams P)
       qa[f][s] = frag_row64(Qs, 32 * w + 16 * f, s, lane);
       da[f][s] = frag_row64(dOs, 32 * w + 16 * f, s, lane);
     }
-  float lse4[2][4], dl4[2][4];
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
+  for (int s = 0; s < 4; ++s) {
+    oT[s] = frag_tr64(dOs, 16 * w, s, lane);     // A[row = d][k = q]
+    qT[s] = frag_tr64(Qs, 16 * w, s, lane);
+  }
+  f32x4 aQ[4][2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = 32 * w + 16 * f + 4 * (lane >> 4) + r;
-      lse4[f][r] = q < P.Tq ? P.lse[((int64_t)g * P.heads + h) * P.Tq + q] : 0.f;
-      dl4[f][r] = delta[q];
-    }
+  for (int df = 0; df < 4; ++df)
 #pragma unroll
-  for (int kg = 0; kg < 2; ++kg) {
-    f32x4 sS[4][2], sP[4][2];
+    for (int f = 0; f < 2; ++f) aQ[df][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- key chunks of 32: phase 1 (wave = 32 query rows) builds Pdrop^T and dS^T [key][q] of the chunk in LDS,
+  // phase 2 adds the chunk to dQ (wave = 32 queries) and finishes dV / dK of its 32 keys (wave = 16 columns)
+  const int nchunks = (P.Tk + 31) >> 5;
+  for (int c = 0; c < nchunks; ++c) {
+    f32x4 sS[2][2], sP[2][2];
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4)
+    for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
       for (int f = 0; f < 2; ++f) { sS[k4][f] = f32x4{0.f, 0.f, 0.f, 0.f}; sP[k4][f] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const bf16x8 kb = frag_row64(Ks, 16 * (4 * kg + k4), s, lane);
-        const bf16x8 vb = frag_row64(Vs, 16 * (4 * kg + k4), s, lane);
+      for (int k4 = 0; k4 < 2; ++k4) {
+        const bf16x8 kb = frag_row64(Ks, 32 * c + 16 * k4, s, lane);
+        const bf16x8 vb = frag_row64(Vs, 32 * c + 16 * k4, s, lane);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-          sS[k4][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[f][s], kb, sS[k4][f], 0, 0, 0);
+          sS[k4][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[f][s], kb, sS[k4][f], 0, 0, 0);   // D[q][key]
           sP[k4][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[f][s], vb, sP[k4][f], 0, 0, 0);
         }
       }
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const int key = 16 * (4 * kg + k4) + (lane & 15);
+    for (int k4 = 0; k4 < 2; ++k4) {
+      const int kl = 16 * k4 + (lane & 15), key = 32 * c + kl;
       const float mk = (mrow && key < P.Tk) ? mrow[key] : 0.f;
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
@@ -307,55 +325,59 @@ __global__ __launch_bounds__(256, 1) void attn_mfma_bwd_kernel(AttnMfmaParams P)
           dsv[r] = pr * (sP[k4][f][r] * mult - dl4[f][r]);
         }
         const int ch = 4 * w + 2 * f + (lane >> 5);
-        const int o = off128(key, ch) + ((lane >> 4) & 1) * 8;
+        const int o = off128(kl, ch) + ((lane >> 4) & 1) * 8;
         store4(reinterpret_cast<bf16_t*>(PdT + o), pdv);
         store4(reinterpret_cast<bf16_t*>(dST + o), dsv);
       }
     }
-  }
-  __syncthreads();
-
-  // ---- phase 2: wave w owns keys 32w.. (dV, dK) and queries 32w.. (dQ) ------------------------
-  f32x4 aV[4][2], aK[4][2], aQ[4][2];
+    __syncthreads();
+    // dQ^T[d][q] += K^T[d][keys of the chunk] dS^T[keys][q]
+    {
+      bf16x8 tb[2];
 #pragma unroll
-  for (int df = 0; df < 4; ++df)
+      for (int f = 0; f < 2; ++f) tb[f] = frag_tr128(dST, 32 * w + 16 * f, 0, lane);    // B[k = key][col = q]
 #pragma unroll
-    for (int f = 0; f < 2; ++f) { aV[df][f] = f32x4{0.f, 0.f, 0.f, 0.f}; aK[df][f] = f32x4{0.f, 0.f, 0.f, 0.f}; aQ[df][f] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int df = 0; df < 4; ++df) {
+        const bf16x8 ka2 = frag_tr64(Ks, 16 * df, c, lane);                              // A[row = d][k = key]
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    bf16x8 pb[2], sb[2], tb[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      pb[f] = frag_row128(PdT, 32 * w + 16 * f, s, lane);   // B[k=q][col=key]
-      sb[f] = frag_row128(dST, 32 * w + 16 * f, s, lane);
-      tb[f] = frag_tr128(dST, 32 * w + 16 * f, s, lane);    // B[k=key][col=q]
-    }
-#pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      const bf16x8 oa = frag_tr64(dOs, 16 * df, s, lane);   // A[row=d][k=q]
-      const bf16x8 qa2 = frag_tr64(Qs, 16 * df, s, lane);
-      const bf16x8 ka2 = frag_tr64(Ks, 16 * df, s, lane);   // A[row=d][k=key]
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        aV[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, pb[f], aV[df][f], 0, 0, 0);
-        aK[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa2, sb[f], aK[df][f], 0, 0, 0);
-        aQ[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka2, tb[f], aQ[df][f], 0, 0, 0);
+        for (int f = 0; f < 2; ++f) aQ[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka2, tb[f], aQ[df][f], 0, 0, 0);
       }
     }
+    // dV^T / dK^T [d = 16w..][key of the chunk] = dO^T / Q^T [d][all q] x Pdrop / dS [q][key]
+    {
+      f32x4 aV[2], aK[2];
+#pragma unroll
+      for (int kf = 0; kf < 2; ++kf) { aV[kf] = f32x4{0.f, 0.f, 0.f, 0.f}; aK[kf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) {
+          const bf16x8 pb = frag_row128(PdT, 16 * kf, s, lane);   // B[k = q][col = key]
+          const bf16x8 sb = frag_row128(dST, 16 * kf, s, lane);
+          aV[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oT[s], pb, aV[kf], 0, 0, 0);
+          aK[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[s], sb, aK[kf], 0, 0, 0);
+        }
+      const int dcol = h * AD + 16 * w + 4 * (lane >> 4);
+#pragma unroll
+      for (int kf = 0; kf < 2; ++kf) {
+        const int key = 32 * c + 16 * kf + (lane & 15);
+        if (key < P.Tk) {
+          store4(P.dv + (kbase + key) * P.ldk + dcol, aV[kf]);
+          f32x4 t = aK[kf];
+          t[0] *= P.scale; t[1] *= P.scale; t[2] *= P.scale; t[3] *= P.scale;
+          store4(P.dk + (kbase + key) * P.ldk + dcol, t);
+        }
+      }
+    }
+    __syncthreads();   // the chunk images are rewritten by the next chunk
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    const int x = 32 * w + 16 * f + (lane & 15);   // key index for dK/dV, query index for dQ
-    const int dcol = h * AD + 4 * (lane >> 4);
+    const int x = 32 * w + 16 * f + (lane & 15);
+    if (x < P.Tq) {
+      const int dcol = h * AD + 4 * (lane >> 4);
 #pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      if (x < P.Tk) {
-        store4(P.dv + (kbase + x) * P.ldk + dcol + 16 * df, aV[df][f]);
-        f32x4 t = aK[df][f];
-        t[0] *= P.scale; t[1] *= P.scale; t[2] *= P.scale; t[3] *= P.scale;
-        store4(P.dk + (kbase + x) * P.ldk + dcol + 16 * df, t);
-      }
-      if (x < P.Tq) {
+      for (int df = 0; df < 4; ++df) {
         f32x4 t = aQ[df][f];
         t[0] *= P.scale; t[1] *= P.scale; t[2] *= P.scale; t[3] *= P.scale;
         store4(P.dq + (qbase + x) * P.ldq + dcol + 16 * df, t);
@@ -397,7 +419,7 @@ extern "C" int fcmf_attn_mfma_bwd(const void* q, const void* k, const void* v, c
   P.dout = (const bf16_t*)dout; P.lse = const_cast<float*>(lse); P.dq = (bf16_t*)dq; P.dk = (bf16_t*)dk; P.dv = (bf16_t*)dv;
   P.G = G; P.heads = heads; P.Tq = Tq; P.Tk = Tk; P.ldq = ldq; P.ldk = ldk; P.ldo = ldo;
   P.scale = scale; P.p = dropout_p; P.seed = seed;
-  const int smem = 8 * TILE_B + 128 * 4;
+  const int smem = 5 * TILE_B;   // Q, K, V, dO tiles + the two 8 KiB chunk images = 80 KiB: two workgroups per CU
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
   hipLaunchKernelGGL(attn_mfma_bwd_kernel, dim3(G * heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
