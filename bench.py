@@ -186,15 +186,23 @@ def main():
     for name, flops, ms in trace:
         e = per.setdefault(name, [0, 0.0, 0.0])
         e[0] += 1; e[1] += flops; e[2] += ms
-    mf = {k: v for k, v in per.items() if k.startswith("gemm_bf16_kernel")}
+    mf = {k: v for k, v in per.items() if k.startswith("gemm_bf16_")}   # the bf16 MFMA kernels (tile256 / tile192 / 128x128)
     roof = None
     if mf:
         dom = max(mf, key=lambda k: mf[k][2])
         n, fl, ms = mf[dom]
         tot_fl, tot_ms = sum(v[1] for v in mf.values()), sum(v[2] for v in mf.values())
         ach = fl / (ms * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from
+        # the committed rocprofv3 counter passes of this same command (tools/pmc_traffic.py -> profiles/), else null
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches=n,
+                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, launches=n,
                     avg_launch_ms=round(ms / n, 4), flops_per_launch=fl / n,
                     all_bf16_gemms=dict(launches=sum(v[0] for v in mf.values()), achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
                                         ms_per_step=round(tot_ms, 3)),

@@ -66,6 +66,10 @@ int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* au
  * 256x256 / 192x256 kernel wherever its preconditions hold */
 void fcmf_gemm_force_tile(int tile);
 
+/* name of the kernel the calling thread's last fcmf_gemm dispatched, e.g. "gemm_bf16_tile256_kernel<0,1,bf16,GELU>"
+ * (benchmarks attribute launch time by it; the string lives in thread-local storage of the library) */
+const char* fcmf_gemm_last_kernel(void);
+
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X dtype = dtype, out float32. */
 int fcmf_colsum(const void* X, float* out, int M, int N, int64_t ldx, int dtype,
                 int accumulate, void* stream);

@@ -6,6 +6,7 @@
 //   gemm_generic_kernel: any dtype / any stride, exact-f32 v_mfma_f32_16x16x4_f32.  Parity path
 //                        (fp32 mode) and odd shapes (classifier N=4, box WG 64->8 ...).
 #include "common.h"
+#include <cstdio>
 
 // Diagnostic build only (make TIMING=1 -> tools/bin/timing/libfcmf_hip.so): wave 0 of workgroup 0 stamps the
 // phases of its first work items with the 100 MHz real-time counter.  No stamp exists in the product build.
@@ -979,6 +980,9 @@ static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipSt
   return FCMF_OK;
 }
 static int g_num_cus = 256;    // MI355X: 8 XCDs x 32 CUs; one persistent 128-KiB-LDS workgroup per CU
+// name of the kernel the last fcmf_gemm call of this thread dispatched (benchmarks attribute time by it)
+static thread_local char g_last_kernel[96] = "";
+extern "C" const char* fcmf_gemm_last_kernel(void) { return g_last_kernel; }
 static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced kernel (benchmarks, tests)
 extern "C" void fcmf_gemm_force_tile(int tile) { g_force_tile = tile; }
 
@@ -1045,6 +1049,11 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       p.tiles = tiles_l;
       p.total_items = tiles_l * p.ksplit;
       dim3 grid(p.total_items < slots ? p.total_items : slots);
+      {
+        static const char* const epi_names[] = {"NONE", "GELU", "TANH", "DGELU", "DTANH", "ADD"};
+        if (tm == 192) snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile192_kernel<%d,%s>", trans_b, epi_names[epilogue]);
+        else snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile256_kernel<%d,%d,%s,%s>", trans_a, trans_b, out_dtype == FCMF_F32 ? "f32" : "bf16", epi_names[epilogue]);
+      }
       if (!trans_a && !trans_b) return launch_bf16_tile<false, false>(p, out_dtype, grid, st, tm);
       if (!trans_a && trans_b) return launch_bf16_tile<false, true>(p, out_dtype, grid, st, tm);
       if (trans_a && !trans_b) return launch_bf16_tile<true, false>(p, out_dtype, grid, st, tm);
@@ -1063,6 +1072,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     p.ktiles_per_split = (nk + ksplit - 1) / ksplit;
     p.ksplit = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
     dim3 grid(tiles, 1, p.ksplit);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_kernel<%d,%d,%s>", trans_a, trans_b, out_dtype == FCMF_F32 ? "f32" : "bf16");
     if (!trans_a && !trans_b) return launch_bf16<false, false>(p, out_dtype, grid, st);
     if (!trans_a && trans_b) return launch_bf16<false, true>(p, out_dtype, grid, st);
     if (trans_a && !trans_b) return launch_bf16<true, false>(p, out_dtype, grid, st);
@@ -1072,6 +1082,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
                   trans_a ? 1 : lda, trans_a ? lda : 1, trans_b ? 1 : ldb, trans_b ? ldb : 1, ldc,
                   epilogue, accumulate, colsum};
   dim3 grid((N + 63) / 64, (M + 63) / 64);
+  snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_generic_kernel");
   if (in_dtype == FCMF_F32 && out_dtype == FCMF_F32)
     hipLaunchKernelGGL((gemm_generic_kernel<float, float>), grid, dim3(256), 0, st, g);
   else if (in_dtype == FCMF_BF16 && out_dtype == FCMF_BF16)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "fcmf_build_info": [],
     "fcmf_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_gemm_force_tile": [_i],
+    "fcmf_gemm_last_kernel": [],
     "fcmf_colsum": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "fcmf_attn_small_fwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp],
     "fcmf_attn_small_bwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -84,7 +85,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args
-            fn.restype = (ctypes.c_char_p if name == "fcmf_build_info" else
+            fn.restype = (ctypes.c_char_p if name in ("fcmf_build_info", "fcmf_gemm_last_kernel") else
                           None if name == "fcmf_gemm_force_tile" else
                           ctypes.c_int64 if name == "fcmf_add_ln_bwd_workspace" else ctypes.c_int)
         _lib = l

@@ -153,17 +153,6 @@ def gemm_trace_end():
     return [(name, fl, e0.elapsed_time(e1)) for name, fl, e0, e1 in tr]
 
 
-def _gemm_kernel_name(A, B, C, bias, aux, M, N, K, lda, ldb, ldc, ta, tb):
-    """mirrors the dispatch rule of fcmf_gemm (csrc/gemm.hip): which kernel serves this call"""
-    al = lambda t: t is None or t.data_ptr() % 16 == 0
-    fast = (A.dtype == torch.bfloat16 and al(A) and al(B) and al(C) and al(aux) and al(bias) and lda % 8 == 0
-            and ldb % 8 == 0 and (M if ta else K) % 8 == 0 and (N if tb else K) % 8 == 0 and N % 4 == 0
-            and ldc % 4 == 0 and K > 0)
-    if not fast:
-        return "gemm_generic_kernel"
-    return f"gemm_bf16_kernel<{int(ta)},{int(tb)},{'f32' if C.dtype == torch.float32 else 'bf16'}>"
-
-
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI_NONE, acc=False, colsum=None):
     H.require_cuda(A, B, C)
     if _gemm_trace is not None:
@@ -173,7 +162,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI
                               int(ta), int(tb), H.dt(A), H.dt(C), epi, int(acc), H.stream()), "fcmf_gemm")
     if _gemm_trace is not None:
         e1.record()
-        _gemm_trace.append((_gemm_kernel_name(A, B, C, bias, aux, M, N, K, lda, ldb, ldc, ta, tb), 2.0 * M * N * K, e0, e1))
+        _gemm_trace.append((H.lib().fcmf_gemm_last_kernel().decode(), 2.0 * M * N * K, e0, e1))
 
 
 def colsum(X, M, N, ldx):

@@ -1,0 +1,71 @@
+"""Per-kernel HBM traffic from two rocprofv3 counter passes (MI355X_MICROARCH.md, HBM / rocprofv3 sections):
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <dirF> -o r01 -- python3 bench.py --steps 2 --warmup 1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d <dirW> -o r01 -- python3 bench.py --steps 2 --warmup 1
+    python tools/pmc_traffic.py <dirF>/r01_counter_collection.csv <dirW>/r01_counter_collection.csv > profiles/r01_pmc_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for wide
+coalesced reads, so it is doubled (the guide's correction) -- WRITE_SIZE is exact for 16-byte stores and float atomics.
+Kernel names are normalised to the names `fcmf_gemm_last_kernel()` reports so that bench.py can look them up."""
+import csv
+import json
+import re
+import sys
+
+EPI = {0: "NONE", 1: "GELU", 2: "TANH", 3: "DGELU", 4: "DTANH", 5: "ADD"}
+B = {"true": 1, "false": 0}
+
+
+def normalise(name):
+    m = re.match(r"_Z\d+(gemm_bf16_tile256_kernel)ILb(\d)ELb(\d)E(f|DF16b)Li(\d)EEv", name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)},{'f32' if m.group(4) == 'f' else 'bf16'},{EPI[int(m.group(5))]}>"
+    m = re.match(r"_Z\d+(gemm_bf16_tile192_kernel)ILb(\d)ELi(\d)EEv", name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{EPI[int(m.group(3))]}>"
+    m = re.match(r"_Z\d+(gemm_bf16_kernel)ILb(\d)ELb(\d)E(f|DF16b)Ev", name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)},{'f32' if m.group(4) == 'f' else 'bf16'}>"
+    m = re.match(r"void (gemm_bf16_tile256_kernel)<(true|false), (true|false), (float|__bf16), (\d)>", name)
+    if m:
+        return f"{m.group(1)}<{B[m.group(2)]},{B[m.group(3)]},{'f32' if m.group(4) == 'float' else 'bf16'},{EPI[int(m.group(5))]}>"
+    m = re.match(r"void (gemm_bf16_tile192_kernel)<(true|false), (\d)>", name)
+    if m:
+        return f"{m.group(1)}<{B[m.group(2)]},{EPI[int(m.group(3))]}>"
+    m = re.match(r"void (gemm_bf16_kernel)<(true|false), (true|false), (float|__bf16)>", name)
+    if m:
+        return f"{m.group(1)}<{B[m.group(2)]},{B[m.group(3)]},{'f32' if m.group(4) == 'float' else 'bf16'}>"
+    # (llvm's demangler garbles exactly one instantiation, <false,false,__bf16,1>, into this string)
+    if name.startswith("void gemm_bf16_tile256_kernel<false, false, bool _Accum, int, E>"):
+        return "gemm_bf16_tile256_kernel<0,0,bf16,GELU>"
+    return re.sub(r"\(.*", "", name)        # other kernels: strip the argument list
+
+
+def collect(path, counter):
+    acc = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            e = acc.setdefault(normalise(row["Kernel_Name"]), [0, 0.0])
+            e[0] += 1
+            e[1] += float(row["Counter_Value"]) * 1024.0
+    return acc
+
+
+def main():
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, [0, 0])[1] + write.get(k, [0, 0])[1])):
+        nf, bf = fetch.get(k, [0, 0.0])
+        nw, bw = write.get(k, [0, 0.0])
+        out[k] = {"launches": max(nf, nw),
+                  "fetch_bytes_per_launch": round(2.0 * bf / max(nf, 1)),      # gfx950: FETCH_SIZE x 2
+                  "write_bytes_per_launch": round(bw / max(nw, 1))}
+        out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE doubled for gfx950; "
+                         "bench.py --steps 2 --warmup 1, B=64 bf16", "kernels": out}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
