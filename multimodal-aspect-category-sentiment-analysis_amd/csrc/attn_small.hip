@@ -1,149 +1,294 @@
 // Two-segment multi-head attention, forward and backward, VALU f32 math, any activation dtype.
-// One workgroup = one (group g, head h).  The T1 shared keys/values are staged once in LDS and
-// reused by all R query rows of the group; the T2 private keys/values of each row stream from
-// global memory.  Used for every attention on the path in fp32 (parity) mode and, in bf16 mode,
-// for the dead-row-pruned fusion layers (1 live query row per image), the 15-token fusion layer,
-// the geometry-biased ROI attention and the IAOG decoder; the bf16 text-encoder attention runs
-// on attn_mfma.hip instead.
+// One workgroup = one (group g, head h).  The T1 shared keys/values and a block of query rows (with dO in
+// the backward) are staged once in LDS; one WAVE owns one query row at a time: its scores over the shared
+// keys run one key per lane out of LDS, its T2 private keys/values stream from global memory one key per
+// step with the head dimension across the lanes (coalesced rows, one wave reduction per key).  The
+// backward is two passes per row block: pass A (wave = row) builds the dropped probabilities and score
+// gradients [row][key] in LDS and finishes dq / dk2 / dv2 / dbias, pass B (wave = shared key) reduces them
+// over the rows into dk1 / dv1 -- two workgroup barriers per row block, no per-row global round trips.
+// Used for every attention on the path in fp32 (parity) mode and, in bf16 mode, for the dead-row-pruned
+// fusion layers (1 live query row per image), the 15-token fusion layer, the geometry-biased ROI attention
+// and the IAOG decoder; the bf16 text-encoder attention runs on attn_mfma.hip instead.
 #include "common.h"
 
-constexpr int AS_MAXT = 256;   // T1 + T2 <= 256 (one key per thread in the backward)
+constexpr int AS_MAXT = 256;   // T1 + T2 <= 256 (keys per lane: 4)
 constexpr int AS_MAXD = 128;   // head dim <= 128 (two elements per lane)
-constexpr int AS_NT1 = 32;     // T1 <= 128: per-thread accumulators cover keys w + 4n, n < 32
+constexpr int AS_NT1 = 32;     // shared keys per backward chunk <= 128: a wave accumulates keys w + 4n, n < 32
 
 struct AttnK {
   fcmf_attn_desc a;
   void* out; float* lse;
   const void* dout; const void* o_in;
   void *dq, *dk1, *dv1, *dk2, *dv2; float* dbias;
+  int RB;                      // query rows staged per block (host: what fits the LDS budget)
+  int TLP;                     // pitch of the per-row key arrays of the backward (max keys a block sees)
+  int KVF;                     // floats occupied by the staged shared K and V images
 };
+
+// stage n rows of a (.., t, h, :) tensor into an f32 LDS image with row pitch `pitch`.  Aligned rows go 16 bytes
+// per lane, several rows per wave instruction, four instructions in flight per wave; otherwise lanes run across
+// the head dimension (coalesced) one row at a time.
+template <typename TT, typename TD>   // TD = float (converted) or TT (raw copy: shared keys/values stay in the activation dtype)
+__device__ __forceinline__ void stage_rows(TD* dst, int pitch, const TT* src, int64_t row_stride, int n, int d, int w, int lane) {
+  constexpr int V = 16 / sizeof(TT);
+  const bool vec = d % V == 0 && row_stride % V == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+  if (vec) {
+    const int lpr = d / V, rpi = 64 / lpr;            // lanes per row, rows per wave instruction
+    const int rl = lane / lpr, ch = lane - rl * lpr;
+    const bool on = rl < rpi;
+    for (int t0 = w * rpi; t0 < n; t0 += 16 * rpi) {   // 4 waves x 4 instructions per round
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * 4 * rpi + rl;
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (on && t < n) v[u] = *reinterpret_cast<const uint4*>(src + (int64_t)t * row_stride + ch * V);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * 4 * rpi + rl;
+        if (on && t < n) {
+          TD* o = dst + t * pitch + ch * V;
+          if constexpr (sizeof(TD) == sizeof(TT)) {
+            *reinterpret_cast<uint4*>(o) = v[u];
+          } else if constexpr (sizeof(TT) == 2) {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(&v[u]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (float)x[j];
+          } else {
+            const float4 x = *reinterpret_cast<const float4*>(&v[u]);
+            o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
+          }
+        }
+      }
+    }
+  } else {
+    for (int t = w; t < n; t += 4) {
+      const TT* sr = src + (int64_t)t * row_stride;
+      for (int c = lane; c < d; c += 64) {
+        if constexpr (sizeof(TD) == sizeof(TT)) dst[t * pitch + c] = sr[c];
+        else dst[t * pitch + c] = to_f32<TT>(sr[c]);
+      }
+    }
+  }
+}
+
+// <x, row> out of LDS (x f32, a broadcast; row in the activation dtype): rows with a 16-byte aligned pitch are
+// read 16 bytes at a time
+template <typename TT>
+__device__ __forceinline__ float lds_dot(const float* __restrict__ x, const TT* __restrict__ row, int d, bool v16) {
+  float s = 0.f;
+  constexpr int V = 16 / sizeof(TT);
+  if (v16) {
+    for (int c = 0; c < d; c += V) {
+      if constexpr (sizeof(TT) == 2) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(row + c);
+        const float4 a0 = *reinterpret_cast<const float4*>(x + c), a1 = *reinterpret_cast<const float4*>(x + c + 4);
+        s += a0.x * (float)b[0] + a0.y * (float)b[1] + a0.z * (float)b[2] + a0.w * (float)b[3] +
+             a1.x * (float)b[4] + a1.y * (float)b[5] + a1.z * (float)b[6] + a1.w * (float)b[7];
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(x + c), b = *reinterpret_cast<const float4*>(row + c);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+      }
+    }
+  } else {
+    for (int c = 0; c < d; ++c) s += x[c] * to_f32<TT>(row[c]);
+  }
+  return s;
+}
+
+// <q, row> and <q2, row2> for one private key held by this lane: the lane walks its own global row with 16-byte
+// loads (all of them independent, so they are in flight together; q comes from LDS as a broadcast)
+template <typename TT>
+__device__ __forceinline__ void dot2_row(const float* __restrict__ qa, const TT* __restrict__ ra, const float* __restrict__ qb,
+                                         const TT* __restrict__ rb, int d, bool vec, float& sa, float& sb) {
+  sa = 0.f; sb = 0.f;
+  constexpr int V = 16 / sizeof(TT);
+  if (vec) {
+    for (int c = 0; c < d; c += V) {
+      if constexpr (sizeof(TT) == 2) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(ra + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sa += qa[c + j] * (float)x[j];
+        if (rb) {
+          const bf16x8 y = *reinterpret_cast<const bf16x8*>(rb + c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sb += qb[c + j] * (float)y[j];
+        }
+      } else {
+        const float4 x = *reinterpret_cast<const float4*>(ra + c);
+        sa += qa[c] * x.x + qa[c + 1] * x.y + qa[c + 2] * x.z + qa[c + 3] * x.w;
+        if (rb) {
+          const float4 y = *reinterpret_cast<const float4*>(rb + c);
+          sb += qb[c] * y.x + qb[c + 1] * y.y + qb[c + 2] * y.z + qb[c + 3] * y.w;
+        }
+      }
+    }
+  } else {
+    for (int c = 0; c < d; ++c) {
+      sa += qa[c] * to_f32<TT>(ra[c]);
+      if (rb) sb += qb[c] * to_f32<TT>(rb[c]);
+    }
+  }
+}
+template <typename TT>
+__device__ __forceinline__ bool private_rows_vectorisable(const fcmf_attn_desc& a) {
+  constexpr int V = 16 / sizeof(TT);
+  return a.T2 > 0 && a.d % V == 0 && a.k2_sg % V == 0 && a.k2_sr % V == 0 && a.k2_st % V == 0 &&
+         (reinterpret_cast<uintptr_t>(a.k2) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.v2) & 15) == 0;
+}
 
 template <typename TT>
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const fcmf_attn_desc& a = P.a;
-  const int d = a.d, T1 = a.T1, T2 = a.T2, T = T1 + T2, dp = d + 1;
-  float* K1s = sm;
-  float* V1s = K1s + T1 * dp;
-  float* qs = V1s + T1 * dp;            // [4][AS_MAXD]
-  float* ps = qs + 4 * AS_MAXD;         // [4][AS_MAXT]
+  const int d = a.d, T1 = a.T1, T2 = a.T2, T = T1 + T2, RB = P.RB;
+  constexpr int V16 = 16 / sizeof(TT);
+  const bool v4 = d % V16 == 0;         // 16-byte LDS accesses throughout
+  const int dp = v4 ? d + V16 : d + 1;  // K/V row pitch (elements): +16 B keeps 16-byte reads of 16 lanes on distinct banks; else odd
+  TT* K1s = reinterpret_cast<TT*>(sm);
+  TT* V1s = K1s + T1 * dp;
+  float* Qs = sm + P.KVF;               // [RB][d] (KVF = floats taken by the two K/V images)
+  float* ps = Qs + RB * d;              // [4][AS_MAXT] probability row of each wave
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
   const int hin = a.head_quirk ? (int)(((int64_t)h * a.G + g) % a.heads) : h;
   const int g2 = g / a.group_div;
   const TT* Q = reinterpret_cast<const TT*>(a.q);
-  const TT* K1 = reinterpret_cast<const TT*>(a.k1);
-  const TT* V1 = reinterpret_cast<const TT*>(a.v1);
   const TT* K2 = reinterpret_cast<const TT*>(a.k2);
   const TT* V2 = reinterpret_cast<const TT*>(a.v2);
   TT* O = reinterpret_cast<TT*>(P.out);
-
-  for (int e = tid; e < T1 * d; e += 256) {
-    int t = e / d, c = e - t * d;
-    int64_t off = (int64_t)g * a.k1_sg + (int64_t)t * a.k1_st + hin * d + c;
-    K1s[t * dp + c] = to_f32<TT>(K1[off]);
-    V1s[t * dp + c] = to_f32<TT>(V1[off]);
+  if (T1 > 0) {
+    stage_rows<TT, TT>(K1s, dp, reinterpret_cast<const TT*>(a.k1) + (int64_t)g * a.k1_sg + hin * d, a.k1_st, T1, d, w, lane);
+    stage_rows<TT, TT>(V1s, dp, reinterpret_cast<const TT*>(a.v1) + (int64_t)g * a.k1_sg + hin * d, a.k1_st, T1, d, w, lane);
   }
-  __syncthreads();
-
   const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
-  const int iters = (a.R + 3) / 4;
-  for (int it = 0; it < iters; ++it) {
-    const int r = it * 4 + w;
-    const bool act = r < a.R;
-    float* q = qs + w * AS_MAXD;
-    float* p = ps + w * AS_MAXT;
-    if (act)
-      for (int c = lane; c < d; c += 64) q[c] = to_f32<TT>(Q[(int64_t)g * a.q_sg + (int64_t)r * a.q_sr + hin * d + c]);
+  float* p = ps + w * AS_MAXT;
+  const bool vec2 = private_rows_vectorisable<TT>(a);
+  for (int rb0 = 0; rb0 < a.R; rb0 += RB) {
+    const int nr = min(RB, a.R - rb0);
+    stage_rows<TT, float>(Qs, d, Q + (int64_t)g * a.q_sg + (int64_t)rb0 * a.q_sr + hin * d, a.q_sr, nr, d, w, lane);
     __syncthreads();
-    float sc[4];
-    float m = -INFINITY;
+    for (int rl = w; rl < nr; rl += 4) {
+      const int r = rb0 + rl;
+      const float* q = Qs + rl * d;
+      float sc[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int t = lane + 64 * n;
-      float s = -INFINITY;
-      if (act && t < T) {
+      for (int n = 0; n < 4; ++n) {
+        const int t = lane + 64 * n;
         float accv = 0.f;
         if (t < T1) {
-          const float* kr = K1s + t * dp;
-          for (int c = 0; c < d; ++c) accv += q[c] * kr[c];
-        } else {
-          const TT* kr = K2 + (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + (int64_t)(t - T1) * a.k2_st + hin * d;
-          for (int c = 0; c < d; ++c) accv += q[c] * to_f32<TT>(kr[c]);
+          accv = lds_dot<TT>(q, K1s + t * dp, d, v4);
+        } else if (t < T) {   // private key: this lane walks its own row
+          float dummy;
+          dot2_row<TT>(q, K2 + (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + (int64_t)(t - T1) * a.k2_st + hin * d, nullptr,
+                       (const TT*)nullptr, d, vec2, accv, dummy);
         }
-        s = accv * a.scale;
-        if (a.mask) s += a.mask[(int64_t)g * T + t];
-        if (a.bias) s += a.bias[(((int64_t)g2 * a.heads + h) * a.R + r) * T + t];
-        if (a.causal && t > r) s = -1e4f;
+        sc[n] = accv;
       }
-      sc[n] = s;
-      m = fmaxf(m, s);
-    }
-    m = wave_max(m);
-    float sum = 0.f;
+      float m = -INFINITY;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int t = lane + 64 * n;
-      float e = (act && t < T) ? __expf(sc[n] - m) : 0.f;
-      sc[n] = e;
-      sum += e;
-    }
-    sum = wave_sum(sum);
-    const float inv = act ? 1.0f / sum : 0.f;
+      for (int n = 0; n < 4; ++n) {
+        const int t = lane + 64 * n;
+        float s = -INFINITY;
+        if (t < T) {
+          s = sc[n] * a.scale;
+          if (a.mask) s += a.mask[(int64_t)g * T + t];
+          if (a.bias) s += a.bias[(((int64_t)g2 * a.heads + h) * a.R + r) * T + t];
+          if (a.causal && t > r) s = -1e4f;
+        }
+        sc[n] = s;
+        m = fmaxf(m, s);
+      }
+      m = wave_max(m);
+      float sum = 0.f;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int t = lane + 64 * n;
-      if (act && t < T) {
-        float pv = sc[n] * inv;
-        if (a.dropout_p > 0.f)
-          pv *= dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * a.R + r) * T + t, a.dropout_p, inv_keep);
-        p[t] = pv;
+      for (int n = 0; n < 4; ++n) {
+        const int t = lane + 64 * n;
+        const float e = t < T ? __expf(sc[n] - m) : 0.f;
+        sc[n] = e;
+        sum += e;
       }
-    }
-    if (act && lane == 0 && P.lse) P.lse[((int64_t)g * a.heads + h) * a.R + r] = m + __logf(sum);
-    __syncthreads();
-    if (act) {
-      for (int c = lane; c < d; c += 64) {
-        float o = 0.f;
-        for (int t = 0; t < T1; ++t) o += p[t] * V1s[t * dp + c];
-        const TT* vb = V2 + (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + hin * d + c;
-        for (int t = 0; t < T2; ++t) o += p[T1 + t] * to_f32<TT>(vb[(int64_t)t * a.k2_st]);
-        O[(int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d + c] = from_f32<TT>(o);
+      sum = wave_sum(sum);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int t = lane + 64 * n;
+        if (t < T) {
+          float pv = sc[n] * inv;
+          if (a.dropout_p > 0.f)
+            pv *= dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * a.R + r) * T + t, a.dropout_p, inv_keep);
+          p[t] = pv;
+        }
       }
+      if (lane == 0 && P.lse) P.lse[((int64_t)g * a.heads + h) * a.R + r] = m + __logf(sum);
+      // out[c] = sum_t p[t] v[t][c]: lanes across the head dimension (p is read back by the wave that wrote it)
+      float o0 = 0.f, o1 = 0.f;
+      {
+        int t = 0;
+        for (; v4 && t + 4 <= T1; t += 4) {
+          const float4 pv = *reinterpret_cast<const float4*>(p + t);
+          const TT* vr = V1s + t * dp;
+          auto f = [&](int i) { return to_f32<TT>(vr[i]); };
+          if (lane < d) o0 += pv.x * f(lane) + pv.y * f(dp + lane) + pv.z * f(2 * dp + lane) + pv.w * f(3 * dp + lane);
+          if (lane + 64 < d) o1 += pv.x * f(lane + 64) + pv.y * f(dp + lane + 64) + pv.z * f(2 * dp + lane + 64) + pv.w * f(3 * dp + lane + 64);
+        }
+        for (; t < T1; ++t) {
+          const float pv = p[t];
+          if (lane < d) o0 += pv * to_f32<TT>(V1s[t * dp + lane]);
+          if (lane + 64 < d) o1 += pv * to_f32<TT>(V1s[t * dp + lane + 64]);
+        }
+      }
+      if (T2 > 0) {
+        const TT* vb = V2 + (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + hin * d;
+#pragma unroll 8
+        for (int t2 = 0; t2 < T2; ++t2) {
+          const float pv = p[T1 + t2];
+          const TT* vr = vb + (int64_t)t2 * a.k2_st;
+          if (lane < d) o0 += pv * to_f32<TT>(vr[lane]);
+          if (lane + 64 < d) o1 += pv * to_f32<TT>(vr[lane + 64]);
+        }
+      }
+      TT* orow = O + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
+      if (lane < d) orow[lane] = from_f32<TT>(o0);
+      if (lane + 64 < d) orow[lane + 64] = from_f32<TT>(o1);
     }
-    __syncthreads();
+    __syncthreads();   // the row block is restaged
   }
 }
 
-// Backward.  grid = (G*heads, ceil(T1/128)): block (.., c) owns the shared keys [128c, 128c+128)
-// (their dK1/dV1 live in registers across the R query rows, so no atomics are needed) and, for
-// c == 0, the private keys.  Each chunk writes its partial dq to dq[c] (dense [chunks,G,R,heads*d]);
-// the host sums the chunks.  dk1/dv1 are dense [G,T1,heads*d].
-template <typename TT>
+// Backward.  grid = (G*heads, ceil(T1/128)): block (.., c) owns the shared keys [128c, 128c+128) (their
+// dK1/dV1 accumulate in registers across the row blocks, so no atomics are needed) and, for c == 0, the
+// private keys.  Each chunk writes its partial dq to dq[c] (dense [chunks,G,R,heads*d]); the host sums the
+// chunks.  dk1/dv1 are dense [G,T1,heads*d].
+// ONE_BLOCK: all R rows fit one staged block (the usual case): dk1/dv1 are final after pass B and go straight
+// to memory; otherwise they accumulate in registers across the row blocks.
+template <typename TT, bool ONE_BLOCK>
 __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const fcmf_attn_desc& a = P.a;
-  const int d = a.d, T1 = a.T1, T2 = a.T2, T = T1 + T2, dp = d + 1;
+  const int d = a.d, T1 = a.T1, T2 = a.T2, T = T1 + T2, RB = P.RB;
+  constexpr int V16 = 16 / sizeof(TT);
+  const bool v4 = d % V16 == 0;
+  const int dp = v4 ? d + V16 : d + 1;
   const int chunk = blockIdx.y, kc0 = chunk * 128;
   const int T1c = min(128, T1 - kc0);                 // shared keys of this chunk (may be <= 0 if T1 == 0)
   const int T2c = chunk == 0 ? T2 : 0;                // private keys are handled by chunk 0
   const int nsh = T1c > 0 ? T1c : 0;
-  float* K1s = sm;
-  float* V1s = K1s + nsh * dp;
-  float* qs = V1s + nsh * dp;       // [AS_MAXD]
-  float* dos = qs + AS_MAXD;        // [AS_MAXD]
-  float* pd = dos + AS_MAXD;        // [256] dropped probabilities: [0,128) shared chunk, [128,256) private
-  float* ds = pd + 256;             // [256] score gradients
-  float* red = ds + 256;            // [4][AS_MAXD] dq partials
-  float* misc = red + 4 * AS_MAXD;  // [4] wave partials of delta
+  const int TL = nsh + T2c;                           // keys this block sees: local index tl
+  TT* K1s = reinterpret_cast<TT*>(sm);
+  TT* V1s = K1s + nsh * dp;
+  float* Qs = sm + P.KVF;            // [RB][d]
+  float* dOs = Qs + RB * d;          // [RB][d]
+  const int TLP = P.TLP;
+  float* PD = dOs + RB * d;          // [RB][TLP] dropped probabilities
+  float* DS = PD + RB * TLP;         // [RB][TLP] score gradients
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
   const int hin = a.head_quirk ? (int)(((int64_t)h * a.G + g) % a.heads) : h;
   const int g2 = g / a.group_div;
   const int64_t HD = (int64_t)a.heads * d;
   const TT* Q = reinterpret_cast<const TT*>(a.q);
-  const TT* K1 = reinterpret_cast<const TT*>(a.k1);
-  const TT* V1 = reinterpret_cast<const TT*>(a.v1);
   const TT* K2 = reinterpret_cast<const TT*>(a.k2);
   const TT* V2 = reinterpret_cast<const TT*>(a.v2);
   const TT* O = reinterpret_cast<const TT*>(P.o_in);
@@ -153,116 +298,159 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
   TT* dV1 = reinterpret_cast<TT*>(P.dv1);
   TT* dK2 = reinterpret_cast<TT*>(P.dk2);
   TT* dV2 = reinterpret_cast<TT*>(P.dv2);
-
-  for (int e = tid; e < nsh * d; e += 256) {
-    int t = e / d, c = e - t * d;
-    int64_t off = (int64_t)g * a.k1_sg + (int64_t)(kc0 + t) * a.k1_st + hin * d + c;
-    K1s[t * dp + c] = to_f32<TT>(K1[off]);
-    V1s[t * dp + c] = to_f32<TT>(V1[off]);
+  if (nsh > 0) {
+    stage_rows<TT, TT>(K1s, dp, reinterpret_cast<const TT*>(a.k1) + (int64_t)g * a.k1_sg + (int64_t)kc0 * a.k1_st + hin * d, a.k1_st, nsh, d, w, lane);
+    stage_rows<TT, TT>(V1s, dp, reinterpret_cast<const TT*>(a.v1) + (int64_t)g * a.k1_sg + (int64_t)kc0 * a.k1_st + hin * d, a.k1_st, nsh, d, w, lane);
   }
-  float accK[AS_NT1][2], accV[AS_NT1][2];
+  constexpr int NACC = ONE_BLOCK ? 1 : AS_NT1;
+  float accK[NACC][2], accV[NACC][2];
 #pragma unroll
-  for (int n = 0; n < AS_NT1; ++n) { accK[n][0] = accK[n][1] = accV[n][0] = accV[n][1] = 0.f; }
-  const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
-  __syncthreads();
-
-  for (int r = 0; r < a.R; ++r) {
-    const int64_t orow = (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
-    float part = 0.f;
-    if (tid < d) {
-      float qv = to_f32<TT>(Q[(int64_t)g * a.q_sg + (int64_t)r * a.q_sr + hin * d + tid]);
-      float dv = to_f32<TT>(dO[orow + tid]);
-      qs[tid] = qv;
-      dos[tid] = dv;
-      part = dv * to_f32<TT>(O[orow + tid]);
-    }
-    part = wave_sum(part);
-    if (lane == 0) misc[w] = part;
-    __syncthreads();
-    const float delta = misc[0] + misc[1] + misc[2] + misc[3];
-    // ---- one key per thread: threads [0,128) shared chunk keys, [128,256) private keys ------
-    {
-      const bool shared_key = tid < 128;
-      const int tl = shared_key ? tid : tid - 128;
-      const bool valid = shared_key ? (tl < nsh) : (tl < T2c);
-      float pdv = 0.f, dsv = 0.f;
-      if (valid) {
-        const int t = shared_key ? kc0 + tl : T1 + tl;  // global key index
-        float s = 0.f, dpd = 0.f;
-        if (shared_key) {
-          const float* kr = K1s + tl * dp;
-          const float* vr = V1s + tl * dp;
-          for (int c = 0; c < d; ++c) { s += qs[c] * kr[c]; dpd += dos[c] * vr[c]; }
-        } else {
-          const int64_t o2 = (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + (int64_t)tl * a.k2_st + hin * d;
-          for (int c = 0; c < d; ++c) { s += qs[c] * to_f32<TT>(K2[o2 + c]); dpd += dos[c] * to_f32<TT>(V2[o2 + c]); }
-        }
-        s *= a.scale;
-        if (a.mask) s += a.mask[(int64_t)g * T + t];
-        if (a.bias) s += a.bias[(((int64_t)g2 * a.heads + h) * a.R + r) * T + t];
-        const bool filled = a.causal && t > r;
-        if (filled) s = -1e4f;
-        const float pr = __expf(s - P.lse[((int64_t)g * a.heads + h) * a.R + r]);
-        float mult = 1.0f;
-        if (a.dropout_p > 0.f)
-          mult = dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * a.R + r) * T + t, a.dropout_p, inv_keep);
-        dsv = filled ? 0.f : pr * (dpd * mult - delta);
-        pdv = pr * mult;
-        if (P.dbias) P.dbias[(((int64_t)g * a.heads + h) * a.R + r) * T + t] = dsv;
-      }
-      pd[tid] = pdv;
-      ds[tid] = dsv;
-    }
-    __syncthreads();
-    // ---- shared-segment accumulators (thread owns chunk keys w+4n, dims lane, lane+64) ------
-    float dq0 = 0.f, dq1 = 0.f;
-    const float q0 = lane < d ? qs[lane] * a.scale : 0.f, q1 = lane + 64 < d ? qs[lane + 64] * a.scale : 0.f;
-    const float o0 = lane < d ? dos[lane] : 0.f, o1 = lane + 64 < d ? dos[lane + 64] : 0.f;
-#pragma unroll
-    for (int n = 0; n < AS_NT1; ++n) {
-      const int t = w + 4 * n;
-      if (t < nsh) {
-        const float dsv = ds[t], pv = pd[t];
-        accK[n][0] += dsv * q0; accK[n][1] += dsv * q1;
-        accV[n][0] += pv * o0;  accV[n][1] += pv * o1;
-        if (lane < d) dq0 += dsv * K1s[t * dp + lane];
-        if (lane + 64 < d) dq1 += dsv * K1s[t * dp + lane + 64];
-      }
-    }
-    // ---- private segment: direct dK2/dV2 writes and the K2 part of dq ------------------------
-    for (int t2 = w; t2 < T2c; t2 += 4) {
-      const float dsv = ds[128 + t2], pv = pd[128 + t2];
-      const int64_t src = (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + (int64_t)t2 * a.k2_st + hin * d;
-      const int64_t dst = (((int64_t)g * a.R + r) * T2 + t2) * HD + h * d;
-      for (int c = lane; c < d; c += 64) {
-        const float kv = to_f32<TT>(K2[src + c]);
-        if (c < 64) dq0 += dsv * kv; else dq1 += dsv * kv;
-        dK2[dst + c] = from_f32<TT>(dsv * a.scale * qs[c]);
-        dV2[dst + c] = from_f32<TT>(pv * dos[c]);
-      }
-    }
-    if (lane < d) red[w * AS_MAXD + lane] = dq0;
-    if (lane + 64 < d) red[w * AS_MAXD + lane + 64] = dq1;
-    __syncthreads();
-    if (tid < d) {
-      float v = red[tid] + red[AS_MAXD + tid] + red[2 * AS_MAXD + tid] + red[3 * AS_MAXD + tid];
-      dQ[((int64_t)g * a.R + r) * HD + h * d + tid] = from_f32<TT>(v * a.scale);
-    }
-    __syncthreads();
-  }
+  for (int n = 0; n < NACC; ++n) { accK[n][0] = accK[n][1] = accV[n][0] = accV[n][1] = 0.f; }
   const bool kv_same = (P.dv1 == nullptr);
+  const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  const bool vec2 = private_rows_vectorisable<TT>(a);
+
+  for (int rb0 = 0; rb0 < a.R; rb0 += RB) {
+    const int nr = min(RB, a.R - rb0);
+    stage_rows<TT, float>(Qs, d, Q + (int64_t)g * a.q_sg + (int64_t)rb0 * a.q_sr + hin * d, a.q_sr, nr, d, w, lane);
+    stage_rows<TT, float>(dOs, d, dO + (int64_t)g * a.o_sg + (int64_t)rb0 * a.o_sr + h * d, a.o_sr, nr, d, w, lane);
+    __syncthreads();
+    // ---- pass A: wave = query row ---------------------------------------------------------------
+    for (int rl = w; rl < nr; rl += 4) {
+      const int r = rb0 + rl;
+      const float* q = Qs + rl * d;
+      const float* dov = dOs + rl * d;
+      float* pd = PD + rl * TLP;
+      float* ds = DS + rl * TLP;
+      const float q0 = lane < d ? q[lane] : 0.f, q1 = lane + 64 < d ? q[lane + 64] : 0.f;
+      const float o0 = lane < d ? dov[lane] : 0.f, o1 = lane + 64 < d ? dov[lane + 64] : 0.f;
+      float delta;
+      {
+        const TT* orow = O + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
+        float part = 0.f;
+        if (lane < d) part = o0 * to_f32<TT>(orow[lane]);
+        if (lane + 64 < d) part += o1 * to_f32<TT>(orow[lane + 64]);
+        delta = wave_sum(part);
+      }
+      // raw scores and dO.v per key: local key tl = lane + 64 n  (shared chunk keys first, then private)
+      float sv[4], dv[4];
+      const int64_t p2 = (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + hin * d;
 #pragma unroll
-  for (int n = 0; n < AS_NT1; ++n) {
-    const int t = w + 4 * n;
-    if (t < nsh) {
-      const int64_t off = ((int64_t)g * T1 + kc0 + t) * HD + h * d;
+      for (int n = 0; n < 4; ++n) {
+        const int tl = lane + 64 * n;
+        float s = 0.f, dpd = 0.f;
+        if (tl < nsh) {
+          s = lds_dot<TT>(q, K1s + tl * dp, d, v4);
+          dpd = lds_dot<TT>(dov, V1s + tl * dp, d, v4);
+        } else if (tl < TL) {   // private key: this lane walks its own rows of K2 and V2
+          const int64_t o2 = p2 + (int64_t)(tl - nsh) * a.k2_st;
+          dot2_row<TT>(q, K2 + o2, dov, V2 + o2, d, vec2, s, dpd);
+        }
+        sv[n] = s; dv[n] = dpd;
+      }
+      const float lse_r = P.lse[((int64_t)g * a.heads + h) * a.R + r];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int tl = lane + 64 * n;
+        if (tl < TL) {
+          const int t = tl < nsh ? kc0 + tl : T1 + (tl - nsh);   // global key index
+          float s = sv[n] * a.scale;
+          if (a.mask) s += a.mask[(int64_t)g * T + t];
+          if (a.bias) s += a.bias[(((int64_t)g2 * a.heads + h) * a.R + r) * T + t];
+          const bool filled = a.causal && t > r;
+          if (filled) s = -1e4f;
+          const float pr = __expf(s - lse_r);
+          float mult = 1.0f;
+          if (a.dropout_p > 0.f)
+            mult = dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * a.R + r) * T + t, a.dropout_p, inv_keep);
+          const float dsv = filled ? 0.f : pr * (dv[n] * mult - delta);
+          pd[tl] = pr * mult;
+          ds[tl] = dsv;
+          if (P.dbias) P.dbias[(((int64_t)g * a.heads + h) * a.R + r) * T + t] = dsv;
+        }
+      }
+      // dq[c] = scale * sum_t ds[t] k[t][c]; private keys also get their dk2 / dv2 rows (outer products)
+      float dq0 = 0.f, dq1 = 0.f;
+      {
+        int tl = 0;
+        for (; v4 && tl + 4 <= nsh; tl += 4) {
+          const float4 dsv = *reinterpret_cast<const float4*>(ds + tl);
+          const TT* kr = K1s + tl * dp;
+          auto f = [&](int i) { return to_f32<TT>(kr[i]); };
+          if (lane < d) dq0 += dsv.x * f(lane) + dsv.y * f(dp + lane) + dsv.z * f(2 * dp + lane) + dsv.w * f(3 * dp + lane);
+          if (lane + 64 < d) dq1 += dsv.x * f(lane + 64) + dsv.y * f(dp + lane + 64) + dsv.z * f(2 * dp + lane + 64) + dsv.w * f(3 * dp + lane + 64);
+        }
+        for (; tl < nsh; ++tl) {
+          const float dsv = ds[tl];
+          if (lane < d) dq0 += dsv * to_f32<TT>(K1s[tl * dp + lane]);
+          if (lane + 64 < d) dq1 += dsv * to_f32<TT>(K1s[tl * dp + lane + 64]);
+        }
+      }
+#pragma unroll 4
+      for (int t2 = 0; t2 < T2c; ++t2) {
+        const float dsv = ds[nsh + t2], pv = pd[nsh + t2];
+        const TT* kr = K2 + p2 + (int64_t)t2 * a.k2_st;
+        const int64_t dst = (((int64_t)g * a.R + r) * T2 + t2) * HD + h * d;
+        if (lane < d) {
+          dq0 += dsv * to_f32<TT>(kr[lane]);
+          dK2[dst + lane] = from_f32<TT>(dsv * a.scale * q0);
+          dV2[dst + lane] = from_f32<TT>(pv * o0);
+        }
+        if (lane + 64 < d) {
+          dq1 += dsv * to_f32<TT>(kr[lane + 64]);
+          dK2[dst + lane + 64] = from_f32<TT>(dsv * a.scale * q1);
+          dV2[dst + lane + 64] = from_f32<TT>(pv * o1);
+        }
+      }
+      TT* dqrow = dQ + ((int64_t)g * a.R + r) * HD + h * d;
+      if (lane < d) dqrow[lane] = from_f32<TT>(dq0 * a.scale);
+      if (lane + 64 < d) dqrow[lane + 64] = from_f32<TT>(dq1 * a.scale);
+    }
+    __syncthreads();
+    // ---- pass B: wave = shared key (w + 4n): reduce over the rows of the block -----------------------
+    auto key_sums = [&](int tl, float& k0, float& k1, float& v0, float& v1) {
+      k0 = k1 = v0 = v1 = 0.f;
+      for (int rl = 0; rl < nr; ++rl) {
+        const float dsv = DS[rl * TLP + tl], pv = PD[rl * TLP + tl];
+        if (lane < d) { k0 += dsv * Qs[rl * d + lane]; v0 += pv * dOs[rl * d + lane]; }
+        if (lane + 64 < d) { k1 += dsv * Qs[rl * d + lane + 64]; v1 += pv * dOs[rl * d + lane + 64]; }
+      }
+      k0 *= a.scale; k1 *= a.scale;
+    };
+    auto write_key = [&](int tl, float k0, float k1, float v0, float v1) {
+      const int64_t off = ((int64_t)g * T1 + kc0 + tl) * HD + h * d;
       if (lane < d) {
-        dK1[off + lane] = from_f32<TT>(kv_same ? accK[n][0] + accV[n][0] : accK[n][0]);
-        if (!kv_same) dV1[off + lane] = from_f32<TT>(accV[n][0]);
+        dK1[off + lane] = from_f32<TT>(kv_same ? k0 + v0 : k0);
+        if (!kv_same) dV1[off + lane] = from_f32<TT>(v0);
       }
       if (lane + 64 < d) {
-        dK1[off + lane + 64] = from_f32<TT>(kv_same ? accK[n][1] + accV[n][1] : accK[n][1]);
-        if (!kv_same) dV1[off + lane + 64] = from_f32<TT>(accV[n][1]);
+        dK1[off + lane + 64] = from_f32<TT>(kv_same ? k1 + v1 : k1);
+        if (!kv_same) dV1[off + lane + 64] = from_f32<TT>(v1);
+      }
+    };
+    if constexpr (ONE_BLOCK) {
+      for (int tl = w; tl < nsh; tl += 4) {
+        float k0, k1, v0, v1;
+        key_sums(tl, k0, k1, v0, v1);
+        write_key(tl, k0, k1, v0, v1);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NACC; ++n) {
+        const int tl = w + 4 * n;
+        if (tl < nsh) {
+          float k0, k1, v0, v1;
+          key_sums(tl, k0, k1, v0, v1);
+          accK[n][0] += k0; accK[n][1] += k1; accV[n][0] += v0; accV[n][1] += v1;
+        }
+      }
+      __syncthreads();   // the row block is restaged
+      if (rb0 + RB >= a.R) {
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) {
+          const int tl = w + 4 * n;
+          if (tl < nsh) write_key(tl, accK[n][0], accK[n][1], accV[n][0], accV[n][1]);
+        }
       }
     }
   }
@@ -279,13 +467,30 @@ static int check_desc(const fcmf_attn_desc* a) {
   return FCMF_OK;
 }
 
+// query rows per staged block: all R if the workgroup then stays within 80 KiB of LDS (two or more workgroups
+// per CU); else blocks of >= 8 rows within 80 KiB if they fit; else as many rows as fit in 160 KiB
+static int rows_per_block(int R, size_t base_bytes, size_t per_row_bytes) {
+  const size_t soft = 80 * 1024, hard = 160 * 1024;
+  if (base_bytes + (size_t)R * per_row_bytes <= soft) return R;
+  if (base_bytes + 8 * per_row_bytes <= soft) return (int)((soft - base_bytes) / per_row_bytes);
+  if (base_bytes + per_row_bytes > hard) return 0;
+  const size_t rb = (hard - base_bytes) / per_row_bytes;
+  return (int)(rb > (size_t)R ? R : rb);
+}
+
 extern "C" int fcmf_attn_small_fwd(const fcmf_attn_desc* desc, void* out, float* lse, void* stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
   if (!out) return FCMF_ERR_ARG;
   AttnK P{};
   P.a = *desc; P.out = out; P.lse = lse;
-  size_t smem = sizeof(float) * (2 * (size_t)desc->T1 * (desc->d + 1) + 4 * AS_MAXD + 4 * AS_MAXT);
+  const size_t esz = desc->dtype == FCMF_F32 ? 4 : 2;
+  P.KVF = (int)((2 * (size_t)desc->T1 * (desc->d + 16 / esz) * esz + 15) / 16 * 4);   // K and V images, rounded to 16 B, in floats
+  const size_t base = sizeof(float) * ((size_t)P.KVF + 4 * AS_MAXT);
+  const size_t per_row = sizeof(float) * (size_t)desc->d;
+  P.RB = rows_per_block(desc->R, base, per_row);
+  if (P.RB <= 0) return FCMF_ERR_UNSUPPORTED;
+  const size_t smem = base + (size_t)P.RB * per_row;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(desc->G * desc->heads);
   if (desc->dtype == FCMF_F32) {
@@ -314,19 +519,27 @@ extern "C" int fcmf_attn_small_bwd(const fcmf_attn_desc* desc, const void* out, 
   P.a = *desc; P.o_in = out; P.dout = dout; P.lse = const_cast<float*>(lse);
   P.dq = dq; P.dk1 = dk1; P.dv1 = dv1; P.dk2 = dk2; P.dv2 = dv2; P.dbias = dbias;
   const int nsh = desc->T1 < 128 ? desc->T1 : 128;
-  size_t smem = sizeof(float) * (2 * (size_t)nsh * (desc->d + 1) + 2 * AS_MAXD + 2 * 256 + 4 * AS_MAXD + 4);
+  const size_t esz = desc->dtype == FCMF_F32 ? 4 : 2;
+  P.KVF = (int)((2 * (size_t)nsh * (desc->d + 16 / esz) * esz + 15) / 16 * 4);
+  const size_t base = sizeof(float) * (size_t)P.KVF;
+  P.TLP = (nsh + desc->T2 + 3) & ~3;   // multiple of 4: rows of the key arrays stay 16-byte aligned
+  const size_t per_row = sizeof(float) * (2 * (size_t)desc->d + 2 * (size_t)P.TLP);
+  P.RB = rows_per_block(desc->R, base, per_row);
+  if (P.RB <= 0) return FCMF_ERR_UNSUPPORTED;
+  const size_t smem = base + (size_t)P.RB * per_row;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nchunks = desc->T1 > 0 ? (desc->T1 + 127) / 128 : 1;
   dim3 grid(desc->G * desc->heads, nchunks);
-  if (desc->dtype == FCMF_F32) {
-    auto k = attn_small_bwd_kernel<float>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, P);
-  } else {
-    auto k = attn_small_bwd_kernel<bf16_t>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, P);
-  }
+  const bool one = P.RB >= desc->R;
+#define LAUNCH_(T, ONE)                                                                                                    \
+  do {                                                                                                                     \
+    auto k = attn_small_bwd_kernel<T, ONE>;                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
+    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, P);                                                                   \
+  } while (0)
+  if (desc->dtype == FCMF_F32) { if (one) LAUNCH_(float, true); else LAUNCH_(float, false); }
+  else { if (one) LAUNCH_(bf16_t, true); else LAUNCH_(bf16_t, false); }
+#undef LAUNCH_
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
