@@ -735,9 +735,13 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       }
       lds_barrier();
       if (atomic) {
+        // the k-splits of one output tile finish together and add into the same lines: every split starts at
+        // a different row of the tile so that concurrent splits touch different lines
         float* Cf = reinterpret_cast<float*>(C);
-        for (int it = 0; it < RPW; ++it) {
-          const int row = wave * RPW + it, gi = i0 + half * 128 + row;
+        const int rot = (w.zsplit * 5) & (RPW - 1);
+        for (int it0 = 0; it0 < RPW; ++it0) {
+          const int it = (it0 + rot) & (RPW - 1);
+          const int row = ((wave + w.zsplit) & (NW - 1)) * RPW + it, gi = i0 + half * 128 + row;
           if (gi >= p.M) continue;
 #pragma unroll
           for (int k = 0; k < GB / 64; ++k) {
