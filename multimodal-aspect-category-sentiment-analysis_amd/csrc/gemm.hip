@@ -513,6 +513,28 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     if (1 < nkt) issue(w, src, 1, base + 1);
     if (2 < nkt) issue(w, src, 2, base + 2);
   }
+  // aux operand of the epilogue (gelu' argument / residual), row layout: 16 B per lane, 8 rows of the wave's
+  // 128x64 sub-tile per instruction, 4 instructions per 32-row round.  Rounds 0 and 1 are requested before the
+  // LAST block of MFMAs of the main loop, the rest right after it (into the dead fragment registers), so the
+  // whole operand is in flight before the epilogue starts.
+  constexpr bool HAS_AUX = sizeof(TC) == 2 && (EPI == FCMF_EPI_DGELU || EPI == FCMF_EPI_ADD);
+  constexpr int NRND = MI / 2;
+  constexpr bool EARLY_AUX = HAS_AUX && MI == 6;   // the 256-row tile has no registers to spare inside the main loop
+  constexpr int NAX = !HAS_AUX ? 1 : (EARLY_AUX ? NRND : 2);   // 256-row tile: a ring of two rounds, refilled as consumed
+  [[maybe_unused]] u32x4 ax[NAX][4];
+  [[maybe_unused]] unsigned aux_base = 0;
+  if constexpr (HAS_AUX) {
+    const int gj_r = j0 + wn * 64 + (lane & 7) * 8;
+    aux_base = gj_r < p.N ? ((unsigned)(i0 + wm * WM + (lane >> 3)) * (unsigned)p.ldc + (unsigned)gj_r) * 2u : 0x80000000u;
+  }
+  auto load_aux = [&](int rnd) __attribute__((always_inline)) {
+    if constexpr (HAS_AUX) {
+      const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, p.c_bytes, 0x00020000);
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        ax[rnd % NAX][it] = __builtin_amdgcn_raw_buffer_load_b128(rX, aux_base + (unsigned)(rnd * 32 + it * 8) * (unsigned)p.ldc * 2u, 0, 0);
+    }
+  };
   // PING-PONG: waves w and w+4 share a SIMD.  Between barrier t and barrier t+1 group A (waves 0-3) feeds
   // (DMA, fragment reads of tile t) THEN multiplies tile t, while group B (waves 4-7) multiplies tile t-1
   // FIRST (fragments read in the previous interval) and feeds tile t afterwards: the SIMD's matrix pipe
@@ -527,6 +549,9 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       if (t == 8) FCMF_STAMP(6);
 #endif
       issue_after_barrier(t);
+      if constexpr (EARLY_AUX) {
+        if (t == nkt - 1) { load_aux(0); load_aux(1); }
+      }
       load_frags(t);
       mma();
     }
@@ -539,7 +564,12 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       issue_after_barrier(t);
       load_frags(t);
     }
+    if constexpr (EARLY_AUX) { load_aux(0); load_aux(1); }
     mma();                                                  // last tile (nkt >= 1 always)
+  }
+  if constexpr (HAS_AUX) {
+#pragma unroll
+    for (int rnd = EARLY_AUX ? 2 : 0; rnd < (EARLY_AUX ? NRND : 2); ++rnd) load_aux(rnd);
   }
   FCMF_STAMP(2);
   const int nbase = base + nkt;                 // ring position of the next item's tile 0
@@ -557,7 +587,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     const int er = lane_e & 15, eg = lane_e >> 4;
     const unsigned ldc2 = (unsigned)p.ldc * 2u;
     const unsigned tile_off = (unsigned)(i0 + wm * WM) * ldc2 + (unsigned)(j0 + wn * 64) * 2u;   // wave's sub-tile
-    constexpr bool HAS_AUX = (EPI == FCMF_EPI_DGELU || EPI == FCMF_EPI_ADD);
     // transposition slice: fragment-layout accesses are 8 B per lane, row-layout accesses 16 B per lane (whole
     // 128-B row pieces, 8 rows per instruction); LDS executes a wave's accesses in order
     char* slice = smem + TNST * TSTAGE_BYTES + wave * 4096;
@@ -576,20 +605,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     const int gj_r = j0 + wn * 64 + rchunk * 8;
     const unsigned sbase = gj_r < p.N ? tile_off + (unsigned)rrow * ldc2 + (unsigned)rchunk * 16u : 0x80000000u;
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.c_bytes, 0x00020000);
-    // aux (gelu' argument / residual) arrives in the row layout too (full cache lines; a fragment-layout global
-    // read would touch 16 lines per instruction), two 32-row rounds ahead of its use, and is turned into the
-    // fragment layout through the slice
-    [[maybe_unused]] u32x4 ax[2][HAS_AUX ? 4 : 1];
-    auto load_aux = [&](int rnd) __attribute__((always_inline)) {
-      if constexpr (HAS_AUX) {
-        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, p.c_bytes, 0x00020000);
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-          ax[rnd & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rX, sbase + (unsigned)(rnd * 32 + it * 8) * ldc2, 0, 0);
-      }
-    };
-    load_aux(0);
-    load_aux(1);
     if constexpr (PREFETCH) {
       const int nxt = item + nblk;
       pre = nxt < p.total_items;
@@ -637,12 +652,13 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       }
     };
     if constexpr (HAS_AUX) {
-      // round by round (32 rows): aux rows -> slice -> fragment layout, math, results -> slice -> rows -> C
+      // round by round (32 rows): aux rows (already in registers, full cache lines: a fragment-layout global read
+      // would touch 16 lines per instruction) -> slice -> fragment layout, math, results -> slice -> rows -> C
 #pragma unroll
       for (int rnd = 0; rnd < MI / 2; ++rnd) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(row_addr(it)) = ax[rnd & 1][it];
-        if (rnd + 2 < MI / 2) load_aux(rnd + 2);
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(row_addr(it)) = ax[rnd % NAX][it];
+        if constexpr (!EARLY_AUX) { if (rnd + 2 < NRND) load_aux(rnd + 2); }
         u32x2 o[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
