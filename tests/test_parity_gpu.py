@@ -230,6 +230,44 @@ def test_full_size_properties_bf16(dev):
         _set(torch.float32)
 
 
+def test_full_size_gradients_shard_additivity_bf16(dev):
+    """BASELINE configs[1] geometry, training graph (dropout off so that the property is exact up to bf16 rounding):
+    the gradient of a batch equals the sum of the gradients of its two halves -- what data parallelism relies on --
+    although the halves run different GEMM kernels (tile-shape cost model, split-K factors depend on the row count)."""
+    model, _ = build_fcmf(synth.BASE_CFG, 7, 36, dev)
+    model.eval()                       # dropout p = 0; gradients still flow
+    _set(torch.bfloat16)
+    try:
+        B = 8
+        b = batch_to(synth.synth_batch(B, synth.BASE_CFG, S=128, num_imgs=7, num_roi=36, seed=11), dev)
+
+        def grads(sl):
+            model.zero_grad(set_to_none=True)
+            part = {k: v[sl] for k, v in b.items()}
+            logits = _run_aspects(model, part)
+            # sum (not mean) of the per-row losses so that shard gradients add up
+            loss = model.loss_aspects(logits, part["labels"]) * logits.shape[0]
+            loss.backward()
+            return {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+        full, lo, hi = grads(slice(0, B)), grads(slice(0, B // 2)), grads(slice(B // 2, B))
+        num = den = 0.0
+        worst = ("", 0.0)
+        for n, g in full.items():
+            if n.endswith("key.bias") or "linears.1.bias" in n:
+                continue               # analytically zero gradients: rounding noise only
+            d = (g - (lo[n] + hi[n])).norm().item()
+            r = d / (g.norm().item() + 1e-12)
+            if g.norm().item() > 1e-6 and r > worst[1]:
+                worst = (n, r)
+            num += d * d
+            den += g.norm().item() ** 2
+        assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+        assert worst[1] < 0.15, worst
+    finally:
+        _set(torch.float32)
+
+
 def test_iaog_tiny_matches_reference(dev):
     from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq
     from fcmf_framework import ops
