@@ -64,6 +64,27 @@ __device__ __forceinline__ bf16x8 frag_tr64p(const char* lds, int c0, int s, int
   o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3]; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
   return o;
 }
+// the same staging in two halves, so that a kernel can put ALL its tile loads in flight before the first LDS write
+// (the fused form exposes one global round trip per tile)
+struct TileRegs { uint4 v[4]; };
+__device__ __forceinline__ TileRegs load_tile(const bf16_t* __restrict__ src, int64_t ld, int rows, int tid) {
+  TileRegs t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, r = c >> 3, c8 = c & 7;
+    t.v[i] = make_uint4(0, 0, 0, 0);
+    if (r < rows) t.v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + c8 * 8);
+  }
+  return t;
+}
+template <bool PERMUTED>
+__device__ __forceinline__ void store_tile(char* lds, const TileRegs& t, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, r = c >> 3, c8 = c & 7;
+    *reinterpret_cast<uint4*>(lds + (PERMUTED ? off64p(r, c8) : off64(r, c8))) = t.v[i];
+  }
+}
 // MFMA operand (rows x0..x0+15, k-step s over the 64 columns) by row read
 __device__ __forceinline__ bf16x8 frag_row64(const char* lds, int x0, int s, int lane) {
   return *reinterpret_cast<const bf16x8*>(lds + off64(x0 + (lane & 15), 4 * s + (lane >> 4)));
@@ -109,15 +130,15 @@ struct AttnMfmaParams {
 };
 
 // =========================================================================================
-__global__ __launch_bounds__(256, 4) void attn_mfma_fwd_kernel(AttnMfmaParams P) {
+__global__ __launch_bounds__(256, 3) void attn_mfma_fwd_kernel(AttnMfmaParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
   const int q0 = blockIdx.y * AT + w * 32;
-  stage_tile(Ks, P.k + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
-  stage_tile_p(Vs, P.v + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
+  const TileRegs kt = load_tile(P.k + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
+  const TileRegs vt = load_tile(P.v + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
 
   // Q fragments straight from global memory in operand layout (16 B per lane)
   bf16x8 qf[2][2];
@@ -130,6 +151,8 @@ __global__ __launch_bounds__(256, 4) void attn_mfma_fwd_kernel(AttnMfmaParams P)
       if (row < P.Tq) v = *reinterpret_cast<const uint4*>(P.q + ((int64_t)g * P.Tq + row) * P.ldq + h * AD + 32 * s + 8 * (lane >> 4));
       qf[f][s] = *reinterpret_cast<bf16x8*>(&v);
     }
+  store_tile<false>(Ks, kt, tid);      // (all of K, V and Q were requested before the first LDS write)
+  store_tile<true>(Vs, vt, tid);
   __syncthreads();
 
   // S^T[key][q]: 8 key fragments x 2 query fragments
@@ -230,10 +253,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(AttnMfmaParams P)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
   const int64_t qbase = (int64_t)g * P.Tq, kbase = (int64_t)g * P.Tk;
-  stage_tile(Qs, P.q + qbase * P.ldq + h * AD, P.ldq, P.Tq, tid);
-  stage_tile(Ks, P.k + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
-  stage_tile(Vs, P.v + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
-  stage_tile(dOs, P.dout + qbase * P.ldo + h * AD, P.ldo, P.Tq, tid);
+  const TileRegs tq = load_tile(P.q + qbase * P.ldq + h * AD, P.ldq, P.Tq, tid);
+  const TileRegs tk = load_tile(P.k + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
+  const TileRegs tv = load_tile(P.v + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
+  const TileRegs td = load_tile(P.dout + qbase * P.ldo + h * AD, P.ldo, P.Tq, tid);
   // delta[q] = sum_d dO[q][d] O[q][d] for the wave's 32 query rows: two lanes per row, then every lane picks
   // the values of the rows its accumulator registers hold (no LDS: the 80 KiB are spoken for)
   float dl4[2][4], lse4[2][4];
@@ -262,6 +285,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(AttnMfmaParams P)
         lse4[f][r] = q2 < P.Tq ? P.lse[((int64_t)g * P.heads + h) * P.Tq + q2] : 0.f;
       }
   }
+  store_tile<false>(Qs, tq, tid);      // (every global read of the prologue was requested before the first LDS write)
+  store_tile<false>(Ks, tk, tid);
+  store_tile<false>(Vs, tv, tid);
+  store_tile<false>(dOs, td, tid);
   __syncthreads();
 
   const float inv_keep = P.p > 0.f ? 1.0f / (1.0f - P.p) : 1.0f;
