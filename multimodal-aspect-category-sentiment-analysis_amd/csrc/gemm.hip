@@ -1,14 +1,16 @@
-// GEMM kernels for gfx950.
-//   gemm_bf16_kernel   : bf16 x bf16 -> f32 accumulate on v_mfma_f32_16x16x32_bf16, 128x128x64
-//                        block tile, 4 waves (2x2), LDS double buffer, XOR-swizzled images,
-//                        transposed operands consumed through ds_read_b64_tr_b16 (so dX = dY*W and
-//                        dW = dY^T*X need no transposed copies), split-K with f32 atomics.
-//   gemm_generic_kernel: any dtype / any stride, exact-f32 v_mfma_f32_16x16x4_f32.  Parity path
-//                        (fp32 mode) and odd shapes (classifier N=4, box WG 64->8 ...).
+// GEMM kernels for gfx950: bf16 x bf16 -> f32 accumulate on v_mfma_f32_16x16x32_bf16, operands row-major in either
+// orientation (transposed operands are consumed through ds_read_b64_tr_b16, so dX = dY*W and dW = dY^T*X need no
+// transposed copies).
+//   gemm_bf16_tile256_kernel / gemm_bf16_tile192_kernel: persistent 256x256 / 192x256 ping-pong kernels for the big
+//                        GEMMs of the step (description further down);
+//   gemm_bf16_kernel   : 128x128x32 block tile, 4 waves (2x2), 4-stage LDS-DMA ring, two workgroups per CU, split-K
+//                        with f32 atomics -- small / ragged / narrow outputs and tanh epilogues;
+//   gemm_generic_kernel: any dtype / any stride, exact-f32 v_mfma_f32_16x16x4_f32.  Parity path (fp32 mode) and odd
+//                        shapes (classifier N=4, box WG 64->8 ...).
 #include "common.h"
 #include <cstdio>
 
-// Diagnostic build only (make TIMING=1 -> tools/bin/timing/libfcmf_hip.so): wave 0 of workgroup 0 stamps the
+// Diagnostic build only (make timing -> tools/bin/timing/libfcmf_hip.so): wave 0 of workgroup 0 stamps the
 // phases of its first work items with the 100 MHz real-time counter.  No stamp exists in the product build.
 #ifdef FCMF_GEMM_TIMING
 __device__ unsigned long long* g_stamp_buf = nullptr;

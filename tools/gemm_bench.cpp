@@ -26,6 +26,8 @@ int main(int argc, char** argv) {
       {"dX   out       NN 49152x768x768", T, 768, 768, 0, 1, FCMF_EPI_NONE, 0, 0},
       {"dX   ffn2+dgelu NN 49152x3072x768", T, 3072, 768, 0, 1, FCMF_EPI_DGELU, 0, 0},
       {"dX   ffn1      NN 49152x768x3072", T, 768, 3072, 0, 1, FCMF_EPI_NONE, 0, 0},
+      {"dX   qkv       NN 49152x768x2304", T, 768, 2304, 0, 1, FCMF_EPI_NONE, 0, 0},
+      {"dX   qkv+add   NN 49152x768x2304", T, 768, 2304, 0, 1, FCMF_EPI_ADD, 0, 0},
       {"dW   768x768   TN k=49152", 768, 768, T, 1, 1, FCMF_EPI_NONE, 1, 1},
       {"dW   3072x768  TN k=49152", 3072, 768, T, 1, 1, FCMF_EPI_NONE, 1, 1},
       {"dW   768x3072  TN k=49152", 768, 3072, T, 1, 1, FCMF_EPI_NONE, 1, 1},
@@ -59,7 +61,7 @@ int main(int argc, char** argv) {
   for (auto& sh : shapes) {
     int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.N : sh.K, ldc = sh.N;
     auto run = [&]() {
-      return fcmf_gemm(A, B, C, sh.acc ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU) ? AUX : nullptr, nullptr,
+      return fcmf_gemm(A, B, C, sh.acc ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU || sh.epi == FCMF_EPI_ADD) ? AUX : nullptr, nullptr,
                        sh.M, sh.N, sh.K, lda, ldb, ldc, sh.ta, sh.tb, FCMF_BF16, sh.out_f32 ? FCMF_F32 : FCMF_BF16, sh.epi, sh.acc, nullptr);
     };
     int rc = run(); rc |= run();
