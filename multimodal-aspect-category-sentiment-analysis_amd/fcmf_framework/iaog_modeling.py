@@ -222,7 +222,7 @@ class IAOGDecoder(nn.Module):
             X, state = blk(X, state, enc_attention_mask=enc_attention_mask, is_train=is_train)
             self._attention_weights[0][i] = blk.attention1.attention_weights
             self._attention_weights[1][i] = blk.attention2.attention_weights
-        return ops.linear(X, self.dense.weight, self.dense.bias)
+        return ops.vocab_linear(X, self.dense.weight, self.dense.bias)
 
     @property
     def attention_weights(self):

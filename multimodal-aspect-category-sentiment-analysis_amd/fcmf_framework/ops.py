@@ -49,18 +49,37 @@ def next_seed():
     return (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
 
 
+VOCAB_PAD = 32   # row padding of ragged 2-D weights (one MFMA k-tile)
+
+
 class _Shadows:
     """bf16 copies of float32 master parameters, keyed by storage address."""
 
     def __init__(self):
         self.map = {}
+        self.pad = {}
+
+    def padded(self, w):
+        """the fresh bf16 copy of a 2-D weight including its zero rows up to a multiple of 32"""
+        sh = self.get(w)
+        return self.pad.get((w.data_ptr(), tuple(w.shape)), sh)
 
     def get(self, w):
         key = (w.data_ptr(), tuple(w.shape))
         ent = self.map.get(key)
         if ent is not None and ent[1] == w._version and not ent[2]:
             return ent[0]
-        sh = ent[0] if ent is not None else torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+        if ent is not None:
+            sh = ent[0]
+        elif w.dim() == 2 and w.shape[0] % VOCAB_PAD != 0:
+            # 2-D weights with a ragged row count (the 64001-row tied vocabulary matrix) get ZERO rows up to the next
+            # multiple of 32 behind the copy: `padded(w)` hands the MFMA kernels a regular [rows32, K] operand
+            rows = (w.shape[0] + VOCAB_PAD - 1) // VOCAB_PAD * VOCAB_PAD
+            full = torch.zeros((rows, w.shape[1]), dtype=torch.bfloat16, device=w.device)
+            sh = full[:w.shape[0]]
+            self.pad[key] = full
+        else:
+            sh = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
         src = w.detach()
         if not src.is_contiguous():
             src = src.contiguous()
@@ -84,6 +103,7 @@ class _Shadows:
 
     def clear(self):
         self.map.clear()
+        self.pad.clear()
 
 
 shadows = _Shadows()
@@ -230,6 +250,60 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, weight, bias=None, act=None):
     return LinearFn.apply(x, weight, bias, act)
+
+
+class VocabLinearFn(torch.autograd.Function):
+    """logits = x W^T + b for a weight whose row count is not a multiple of 8 (IAOG: the tied 64001 x 768
+    vocabulary matrix, fcmf_pretraining.py:159-166), bf16 mode: every GEMM runs on the MFMA kernels over the
+    row-padded weight copy and column-padded logits / logit gradients (the padding columns are exact zeros);
+    without it all three GEMMs of the projection fall to the any-stride f32-MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = _rows(x)
+        V, K = weight.shape
+        wp = shadows.padded(weight)                       # [Vp, K] bf16, rows >= V zero
+        Vp = wp.shape[0]
+        M = x2.shape[0]
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(Vp, dtype=torch.float32, device=x2.device)
+            bp[:V] = bias.detach()
+        y = torch.empty((M, Vp), dtype=x2.dtype, device=x2.device)
+        gemm(x2, wp, y, M, Vp, K, _ld(x2), K, Vp, 0, 0, bias=bp)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return y[:, :V].reshape(*x.shape[:-1], V)          # one compaction copy: consumers see the reference shape
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        V, K = weight.shape
+        wp = shadows.padded(weight)
+        Vp = wp.shape[0]
+        M = x2.shape[0]
+        dyp = torch.zeros((M, Vp), dtype=x2.dtype, device=x2.device)
+        dyp[:, :V] = dy.reshape(M, V)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
+            gemm(dyp, wp, dx, M, K, Vp, Vp, K, K, 0, 1)
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((Vp, K), dtype=torch.float32, device=x2.device)
+            gemm(dyp, x2, dwp, Vp, K, M, Vp, _ld(x2), K, 1, 1, acc=True)
+            dw = dwp[:V]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dyp, M, Vp, Vp)[:V]
+        return dx, dw, db
+
+
+def vocab_linear(x, weight, bias=None):
+    """nn.Linear onto a vocabulary: the padded MFMA path for ragged vocabularies in bf16 mode, else `linear`"""
+    if compute_dtype() == torch.bfloat16 and x.dtype == torch.bfloat16 and weight.shape[0] % VOCAB_PAD != 0:
+        return VocabLinearFn.apply(x, weight, bias)
+    return LinearFn.apply(x, weight, bias, None)
 
 
 class FFNFn(torch.autograd.Function):

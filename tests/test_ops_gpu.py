@@ -153,6 +153,44 @@ def test_gemm_strided_rows(dev):
     assert rel_err(y, x[:, 0].cpu() @ w.cpu().t()) < 2e-5
 
 
+def test_vocab_linear_ragged_vocabulary_bf16(dev):
+    """IAOG vocabulary projection (64001 rows in the reference: not a multiple of 8): the padded MFMA path must
+    give the same logits and gradients as a plain linear layer, and leave the padding rows of the shadow at zero
+    after an optimizer step refreshed it"""
+    ops, H = _ops()
+    from fcmf_framework.optimization import FusedAdamW
+    V, K, M = 1003, 64, 70
+    ops.set_compute_dtype(torch.bfloat16)
+    ops.shadows.clear()
+    try:
+        w = torch.nn.Parameter(_rand((V, K), dev, seed=1) * 0.3)
+        b = torch.nn.Parameter(_rand((V,), dev, seed=2))
+        x = _rand((5, 14, K), dev, torch.bfloat16, seed=3).requires_grad_(True)
+        y = ops.vocab_linear(x, w, b)
+        assert y.shape == (5, 14, V)
+        g = _rand(y.shape, dev, torch.bfloat16, seed=4)
+        (y.float() * g.float()).sum().backward()
+        xr = x.detach().float().cpu().requires_grad_(True)
+        wr = w.detach().cpu().to(torch.bfloat16).float().requires_grad_(True)
+        br = b.detach().cpu().clone().requires_grad_(True)
+        ref = xr @ wr.t() + br
+        (ref * g.float().cpu()).sum().backward()
+        assert rel_err(y, ref) < 2e-2
+        assert rel_err(x.grad, xr.grad) < 2e-2
+        assert rel_err(w.grad, wr.grad) < 2e-2
+        assert rel_err(b.grad, br.grad) < 2e-2
+        pad = ops.shadows.padded(w)
+        assert pad.shape[0] % 32 == 0 and pad.shape[0] >= V and float(pad[V:].abs().max()) == 0.0
+        opt = FusedAdamW([w, b], lr=1e-2)
+        opt.step(max_grad_norm=1.0)
+        pad2 = ops.shadows.padded(w)
+        assert pad2.data_ptr() == pad.data_ptr() and float(pad2[V:].abs().max()) == 0.0
+        assert rel_err(pad2[:V], w.detach().to(torch.bfloat16)) < 1e-6
+    finally:
+        ops.set_compute_dtype(torch.float32)
+        ops.shadows.clear()
+
+
 def test_colsum(dev):
     ops, H = _ops()
     for dtype in (torch.float32, torch.bfloat16):
