@@ -1042,8 +1042,10 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     const bool tile_ok = (N % 8 == 0) && (ldc % 8 == 0) && (out_dtype == FCMF_BF16 || epilogue == FCMF_EPI_NONE) &&
                          epilogue != FCMF_EPI_TANH && epilogue != FCMF_EPI_DTANH &&
                          (out_dtype == FCMF_F32 || c_extent < (1ll << 31));
+    // (weight gradients: the 256x256 kernel's row-wise f32 epilogue / 256-byte atomics beat the 128x128 kernel's
+    // fragment-layout atomics from K = 1024 up -- 25 vs 97 us at 768x768x2048)
     bool large = tile_ok && M >= 256 && N >= 256 &&
-                 ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && (int64_t)M * N * K >= (1ll << 33)));
+                 ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && K >= 1024));
     if (g_force_tile == 128) large = false;
     if (g_force_tile == 256 || g_force_tile == 192) large = tile_ok;
     if (large) {

@@ -34,6 +34,13 @@ int main(int argc, char** argv) {
       {"fwd  vismap    NT 21952x768x2048", 21952, 768, 2048, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"sq   NT 4096^3", 4096, 4096, 4096, 0, 0, FCMF_EPI_NONE, 0, 0},
 
+      {"small NT 2048x768x768", 2048, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"small NT 2048x3072x768", 2048, 3072, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"small NT 2048x768x3072", 2048, 768, 3072, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"small NN 2048x768x768", 2048, 768, 768, 0, 1, FCMF_EPI_NONE, 0, 0},
+      {"small dW 768x768 TN k=2048", 768, 768, 2048, 1, 1, FCMF_EPI_NONE, 1, 1},
+      {"small dW 3072x768 TN k=2048", 3072, 768, 2048, 1, 1, FCMF_EPI_NONE, 1, 1},
+      {"small NT 2688x768x768", 2688, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"scan NT 49152x3072 K=256", T, 3072, 256, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"scan NT 49152x3072 K=512", T, 3072, 512, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"scan NT 49152x3072 K=1536", T, 3072, 1536, 0, 0, FCMF_EPI_NONE, 0, 0},
