@@ -354,7 +354,7 @@ extern "C" int fcmf_add_ln_fwd(const void* x, const void* res, int64_t res_strid
 
 static int ln_bwd_blocks(int rows) {
   int blocks = (rows + 3) / 4;
-  return blocks > 2048 ? 2048 : blocks;   // 8 waves per SIMD-quad keep enough rows in flight to reach the HBM rate
+  return blocks > 1024 ? 1024 : blocks;   // 4 workgroups per CU keep enough rows in flight; fewer partial rows for the reduce pass
 }
 
 extern "C" int64_t fcmf_add_ln_bwd_workspace(int rows, int H) { return (int64_t)ln_bwd_blocks(rows) * 3 * H; }
