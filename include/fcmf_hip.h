@@ -66,6 +66,12 @@ int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* au
  * 256x256 / 192x256 kernel wherever its preconditions hold */
 void fcmf_gemm_force_tile(int tile);
 
+/* Optional caller-owned scratch for split-K weight-gradient GEMMs issued on `stream`: with at least
+ * ksplit*M*N*4 bytes registered the k-split partial tiles are written with plain stores and summed by a reduce
+ * pass (5x cheaper than 65 536 float atomics per CU); without it, or when it is too small, the GEMM uses float
+ * atomics.  ptr = NULL unregisters.  The buffer must stay valid until the stream has drained. */
+int fcmf_gemm_set_workspace(void* ptr, int64_t bytes, void* stream);
+
 /* name of the kernel the calling thread's last fcmf_gemm dispatched, e.g. "gemm_bf16_tile256_kernel<0,1,bf16,GELU>"
  * (benchmarks attribute launch time by it; the string lives in thread-local storage of the library) */
 const char* fcmf_gemm_last_kernel(void);

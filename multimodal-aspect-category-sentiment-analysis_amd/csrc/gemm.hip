@@ -9,6 +9,8 @@
 //                        shapes (classifier N=4, box WG 64->8 ...).
 #include "common.h"
 #include <cstdio>
+#include <mutex>
+#include <unordered_map>
 
 // Diagnostic build only (make timing -> tools/bin/timing/libfcmf_hip.so): wave 0 of workgroup 0 stamps the
 // phases of its first work items with the 100 MHz real-time counter.  No stamp exists in the product build.
@@ -33,6 +35,7 @@ struct GemmParams {
   unsigned c_bytes;            // extent of C (and aux) in bytes, tile kernels with 2-byte outputs
   float* colsum;               // optional: colsum[n] += sum_m C[m,n] (bias gradient of the producing layer)
   int tiles, total_items;      // persistent big kernel: output tiles, tiles x k-splits
+  float* ws;                   // split-K partial tiles [ksplit][M][N] (plain stores + a reduce pass) or null (float atomics)
 };
 
 // bf16-output epilogues use odd polynomials instead of erf/exp (no transcendental issue slots, no
@@ -730,8 +733,12 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     // accumulators -> LDS (f32, one 128-row half at a time, the whole ring) -> row-wise output with
     // whole-row stores or 256-byte float atomics for split-K
     constexpr int LPR = GB / 8, RPI = 64 / LPR, RPW = 128 / NW;
-    const bool atomic = (p.ksplit > 1);
+    const bool to_ws = p.ws != nullptr && p.ksplit > 1;     // k-split partials go to the workspace with plain stores
+    const bool atomic = (p.ksplit > 1) && !to_ws;
     const bool lead = (w.zsplit == 0);
+    float* Cout = to_ws ? p.ws + (int64_t)w.zsplit * p.M * p.N : reinterpret_cast<float*>(C);
+    const int64_t ldo = to_ws ? (int64_t)p.N : p.ldc;
+    const bool rmw = p.accumulate && !to_ws;                // (the reduce pass adds the old C once)
     float* Ct = reinterpret_cast<float*>(smem);   // [128][256] f32; 16-B chunk index XOR (row & 7)
     int lane_e = lane;                          // (laundered, as in the bf16 epilogue)
     asm volatile("" : "+v"(lane_e));
@@ -777,8 +784,8 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
           const f32x4 lo = *reinterpret_cast<const f32x4*>(Ct + row * GB + ((c0 ^ (row & 7)) << 2));
           const f32x4 hi = *reinterpret_cast<const f32x4*>(Ct + row * GB + (((c0 + 1) ^ (row & 7)) << 2));
           f32x2 v[4] = {f32x2{lo[0], lo[1]} + bv[0], f32x2{lo[2], lo[3]} + bv[1], f32x2{hi[0], hi[1]} + bv[2], f32x2{hi[2], hi[3]} + bv[3]};
-          float* cf = reinterpret_cast<float*>(C) + (int64_t)gi * p.ldc + gj;
-          if (p.accumulate) {
+          float* cf = Cout + (int64_t)gi * ldo + gj;
+          if (rmw) {
             f32x2 o[4];
             load8f(cf, o);
 #pragma unroll
@@ -1001,6 +1008,30 @@ static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipSt
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
+// C (+)= sum_z ws[z]: the reduce pass of the workspace split-K (partials were just written: L2 / Infinity Cache hits)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
+                                                            int64_t ldc, int ksplit, int accumulate) {
+  const int64_t total4 = (int64_t)M * N / 4;           // N % 8 == 0 on this path
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t e = i * 4, row = e / N, col = e - row * N;
+    f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(C + row * ldc + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int z = 0; z < ksplit; ++z) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)z * M * N + e);
+    *reinterpret_cast<f32x4*>(C + row * ldc + col) = s;
+  }
+}
+
+// caller-owned split-K workspaces, one per stream (a GEMM on a stream without one uses float atomics)
+struct Workspace { float* ptr; int64_t bytes; };
+static std::mutex g_ws_mutex;
+static std::unordered_map<void*, Workspace> g_ws;
+extern "C" int fcmf_gemm_set_workspace(void* ptr, int64_t bytes, void* stream) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  if (!ptr || bytes <= 0) g_ws.erase(stream);
+  else g_ws[stream] = Workspace{reinterpret_cast<float*>(ptr), bytes};
+  return FCMF_OK;
+}
+
 static int g_num_cus = 256;    // MI355X: 8 XCDs x 32 CUs; one persistent 128-KiB-LDS workgroup per CU
 // name of the kernel the last fcmf_gemm call of this thread dispatched (benchmarks attribute time by it)
 static thread_local char g_last_kernel[96] = "";
@@ -1030,7 +1061,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
                     (trans_a || K % BK == 0) && (trans_b || K % BK == 0) &&
                     (((int64_t)(trans_a ? K : M) * lda) < (1ll << 30)) && (((int64_t)(trans_b ? K : N) * ldb) < (1ll << 30));
   if (fast) {
-    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, 0, colsum, 0, 0};
+    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr};
     // bytes addressable through each operand: (rows - 1) * ld + contiguous extent
     p.a_bytes = (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
     p.b_bytes = (unsigned)((((int64_t)(trans_b ? K : N) - 1) * ldb + (trans_b ? N : K)) * 2);
@@ -1073,15 +1104,30 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       p.tiles = tiles_l;
       p.total_items = tiles_l * p.ksplit;
       dim3 grid(p.total_items < slots ? p.total_items : slots);
+      p.ws = nullptr;
+      if (p.ksplit > 1) {
+        std::lock_guard<std::mutex> lock(g_ws_mutex);
+        auto it = g_ws.find(stream);
+        if (it != g_ws.end() && it->second.bytes >= (int64_t)p.ksplit * M * N * 4) p.ws = it->second.ptr;
+      }
       {
         static const char* const epi_names[] = {"NONE", "GELU", "TANH", "DGELU", "DTANH", "ADD"};
         if (tm == 192) snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile192_kernel<%d,%s>", trans_b, epi_names[epilogue]);
         else snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile256_kernel<%d,%d,%s,%s>", trans_a, trans_b, out_dtype == FCMF_F32 ? "f32" : "bf16", epi_names[epilogue]);
       }
-      if (!trans_a && !trans_b) return launch_bf16_tile<false, false>(p, out_dtype, grid, st, tm);
-      if (!trans_a && trans_b) return launch_bf16_tile<false, true>(p, out_dtype, grid, st, tm);
-      if (trans_a && !trans_b) return launch_bf16_tile<true, false>(p, out_dtype, grid, st, tm);
-      return launch_bf16_tile<true, true>(p, out_dtype, grid, st, tm);
+      int rc;
+      if (!trans_a && !trans_b) rc = launch_bf16_tile<false, false>(p, out_dtype, grid, st, tm);
+      else if (!trans_a && trans_b) rc = launch_bf16_tile<false, true>(p, out_dtype, grid, st, tm);
+      else if (trans_a && !trans_b) rc = launch_bf16_tile<true, false>(p, out_dtype, grid, st, tm);
+      else rc = launch_bf16_tile<true, true>(p, out_dtype, grid, st, tm);
+      if (rc == FCMF_OK && p.ws) {
+        const int64_t total4 = (int64_t)M * N / 4;
+        const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, reinterpret_cast<float*>(C), M, N, ldc,
+                           p.ksplit, accumulate);
+        FCMF_CHECK_LAUNCH();
+      }
+      return rc;
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int ksplit = 1;

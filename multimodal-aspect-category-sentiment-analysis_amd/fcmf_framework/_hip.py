@@ -38,6 +38,7 @@ SIGNATURES = {
     "fcmf_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_gemm_force_tile": [_i],
     "fcmf_gemm_last_kernel": [],
+    "fcmf_gemm_set_workspace": [_vp, _i64, _vp],
     "fcmf_colsum": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "fcmf_attn_small_fwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp],
     "fcmf_attn_small_bwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

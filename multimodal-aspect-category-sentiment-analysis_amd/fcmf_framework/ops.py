@@ -173,8 +173,24 @@ def gemm_trace_end():
     return [(name, fl, e0.elapsed_time(e1)) for name, fl, e0, e1 in tr]
 
 
+SPLITK_WORKSPACE_BYTES = 96 << 20   # >= ksplit*M*N*4 of every weight-gradient GEMM of FCMF-base (66 MB for 768x768 x 28 splits)
+_splitk_ws = {}
+
+
+def _ensure_splitk_workspace(device):
+    """one scratch buffer per (device, stream) for the split-K partial tiles of the weight-gradient GEMMs"""
+    st = H.stream()
+    key = (device.index, st)
+    if key not in _splitk_ws:
+        buf = torch.empty(SPLITK_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        H.check(H.lib().fcmf_gemm_set_workspace(H.ptr(buf), buf.numel(), st), "fcmf_gemm_set_workspace")
+        _splitk_ws[key] = buf
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI_NONE, acc=False, colsum=None):
     H.require_cuda(A, B, C)
+    if acc:
+        _ensure_splitk_workspace(C.device)
     if _gemm_trace is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

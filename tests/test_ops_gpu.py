@@ -142,6 +142,30 @@ def test_gemm_weight_grad_splitk(dev, dtype, Mtok):
     assert rel_err(dW, ref) < 1e-4 if dtype == torch.float32 else rel_err(dW, ref) < 2e-3
 
 
+@pytest.mark.parametrize("workspace", [True, False])
+def test_gemm_weight_grad_splitk_workspace_and_atomics(dev, workspace):
+    """the persistent kernel's two split-K reductions (partial tiles in a registered workspace + reduce pass, float
+    atomics without one) give the same weight gradient; 9 tiles x 8 splits, ragged token count"""
+    ops, H = _ops()
+    N, K, Mtok = 768, 768, 8200
+    dY, X = _rand((Mtok, N), dev, torch.bfloat16, seed=1), _rand((Mtok, K), dev, torch.bfloat16, seed=2)
+    dW = torch.ones((N, K), dtype=torch.float32, device=dev)
+    st = H.stream()
+    try:
+        if not workspace:
+            ops._ensure_splitk_workspace(dev)
+            H.check(H.lib().fcmf_gemm_set_workspace(None, 0, st), "unregister")
+            H.check(H.lib().fcmf_gemm(H.ptr(dY), H.ptr(X), H.ptr(dW), None, None, None, N, K, Mtok, N, K, K, 1, 1,
+                                      H.dt(dY), H.dt(dW), H.EPI_NONE, 1, st), "fcmf_gemm")
+        else:
+            ops.gemm(dY, X, dW, N, K, Mtok, N, K, K, 1, 1, acc=True)
+        assert H.lib().fcmf_gemm_last_kernel().decode() == "gemm_bf16_tile256_kernel<1,1,f32,NONE>"
+        ref = dY.float().cpu().t() @ X.float().cpu() + 1.0
+        assert rel_err(dW, ref) < 2e-3
+    finally:
+        ops._splitk_ws.clear()          # the next accumulate GEMM registers a fresh workspace
+
+
 def test_gemm_strided_rows(dev):
     """A row stride > K: the pooler's row-0 gather (mm_modeling.py:428) is just lda = S*H"""
     ops, H = _ops()

@@ -64,6 +64,11 @@ int main(int argc, char** argv) {
     hipMemset(bias, 0, 4096 * 4);
     hipMemset(C, 0, maxC * 4);
   }
+  if (!getenv("FCMF_BENCH_NO_WS")) {   // split-K workspace (plain stores + reduce pass instead of float atomics)
+    void* ws; const size_t wsb = 96u << 20;
+    hipMalloc(&ws, wsb);
+    fcmf_gemm_set_workspace(ws, (int64_t)wsb, nullptr);
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (auto& sh : shapes) {
     int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.N : sh.K, ldc = sh.N;
