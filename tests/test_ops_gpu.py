@@ -265,6 +265,8 @@ ATTN_CASES = [
     (2, 5, 4, 16, 170, 0, 1, True, False, False),     # T1 > 128: two backward key chunks
     (2, 7, 2, 64, 128, 36, 1, True, False, False),    # the pruned mm layer geometry
     (3, 6, 4, 16, 6, 0, 1, False, False, True),       # causal fill (IAOG decoder)
+    (1, 150, 2, 64, 130, 20, 1, True, False, False),  # rows staged in several blocks x two key chunks x private keys
+    (2, 40, 3, 20, 33, 5, 2, True, True, False),      # head dim not a multiple of 8: scalar staging / dot paths, bias + groups
 ]
 
 
