@@ -166,10 +166,15 @@ int fcmf_embed_ln_fwd(const int64_t* ids, const int64_t* pos, const int64_t* typ
                       const float* gamma, const float* beta, void* y, void* z, float* mean,
                       float* rstd, int ntok, int H, float eps, float dropout_p, uint64_t seed,
                       int dtype, void* stream);
-/* scatter-add dz into the float32 table gradients (pad rows of word/pos receive nothing). */
+/* scatter-add dz into the float32 table gradients (pad rows of word/pos receive nothing).  dpos may be NULL when
+ * the position table is handled by fcmf_embed_pos_bwd. */
 int fcmf_embed_bwd(const void* dz, const int64_t* ids, const int64_t* pos, const int64_t* type_ids,
                    float* dword, float* dpos, float* dtype_table, int ntok, int H, int pad_id,
                    int dtype, void* stream);
+/* position-table gradient for tokens laid out [nseq, S]: same result as the dpos part of fcmf_embed_bwd (ACCUMULATED
+ * into dpos), summed per sequence offset in registers first -- the offsets of all sequences share position rows. */
+int fcmf_embed_pos_bwd(const void* dz, const int64_t* pos, float* dpos, int nseq, int S, int H, int pad_id,
+                       int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Box geometry (roi_modeling.py:79-138,161-163 and the log-clamp of :40), fused:

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dz
       float* w = dword + id * H + c;
       atomicAdd(w + 0, d.x); atomicAdd(w + 1, d.y); atomicAdd(w + 2, d.z); atomicAdd(w + 3, d.w);
     }
-    if (ps != pad_id) {
+    if (dpos && ps != pad_id) {
       float* q = dpos + ps * H + c;
       atomicAdd(q + 0, d.x); atomicAdd(q + 1, d.y); atomicAdd(q + 2, d.z); atomicAdd(q + 3, d.w);
     }
@@ -316,6 +316,31 @@ __global__ __launch_bounds__(256) void embed_type0_kernel(const T* __restrict__ 
   red[w][lane] = s;
   __syncthreads();
   if (w == 0 && col < H) atomicAdd(dtt + col, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+// position-table gradient, one workgroup per (sequence offset s, 256 columns): the tokens at offset s of all
+// sequences nearly always share one position id (RoBERTa ids count the non-pad prefix), so their rows are summed in
+// registers (64 sequences per workgroup) and leave as ONE atomic per column; tokens with another id fall back to
+// their own atomics.  (The
+// per-token scatter of embed_bwd_kernel makes every sequence hit the same <= S rows: 384-way contention at B=64.)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const T* __restrict__ dz, const int64_t* __restrict__ pos,
+                                                            float* __restrict__ dpos, int nseq, int S, int H, int pad_id) {
+  const int s = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= H) return;
+  int64_t p0 = -1;
+  float acc = 0.f;
+  const int g0 = blockIdx.z * 64, g1 = min(nseq, g0 + 64);      // 64 sequences per workgroup
+#pragma unroll 8
+  for (int g = g0; g < g1; ++g) {
+    const int64_t row = (int64_t)g * S + s, id = pos[row];
+    if (id == pad_id) continue;
+    const float d = to_f32<T>(dz[row * H + c]);
+    if (p0 < 0) p0 = id;
+    if (id == p0) acc += d;
+    else atomicAdd(dpos + id * H + c, d);
+  }
+  if (p0 >= 0) atomicAdd(dpos + p0 * H + c, acc);
 }
 
 // pick the smallest pass count NP (256 columns per pass) that covers H
@@ -407,7 +432,7 @@ extern "C" int fcmf_embed_ln_fwd(const int64_t* ids, const int64_t* pos, const i
 
 extern "C" int fcmf_embed_bwd(const void* dz, const int64_t* ids, const int64_t* pos, const int64_t* type_ids, float* dword,
                               float* dpos, float* dtype_table, int ntok, int H, int pad_id, int dtype, void* stream) {
-  if (!dz || !ids || !pos || !dword || !dpos) return FCMF_ERR_ARG;
+  if (!dz || !ids || !pos || !dword) return FCMF_ERR_ARG;     // dpos may be NULL: see fcmf_embed_pos_bwd
   if (H % 4 != 0) return FCMF_ERR_UNSUPPORTED;
   if (ntok <= 0) return ntok == 0 ? FCMF_OK : FCMF_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -421,6 +446,19 @@ extern "C" int fcmf_embed_bwd(const void* dz, const int64_t* ids, const int64_t*
     hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dz, ids, pos, type_ids, dword, dpos, dtype_table, ntok, H, pad_id);
     if (dtype_table) hipLaunchKernelGGL((embed_type0_kernel<bf16_t>), g2, dim3(256), 0, st, (const bf16_t*)dz, type_ids, dtype_table, ntok, H, rpb);
   } else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_embed_pos_bwd(const void* dz, const int64_t* pos, float* dpos, int nseq, int S, int H, int pad_id,
+                                  int dtype, void* stream) {
+  if (!dz || !pos || !dpos || nseq < 0 || S <= 0 || H <= 0) return FCMF_ERR_ARG;
+  if (nseq == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(S, (H + 255) / 256, (nseq + 63) / 64);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((embed_pos_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dz, pos, dpos, nseq, S, H, pad_id);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((embed_pos_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dz, pos, dpos, nseq, S, H, pad_id);
+  else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }

@@ -484,8 +484,12 @@ class EmbedLNFn(torch.autograd.Function):
         dword = torch.zeros(ws, dtype=torch.float32, device=z.device)
         dpos = torch.zeros(ps, dtype=torch.float32, device=z.device)
         dtt = torch.zeros(ts, dtype=torch.float32, device=z.device)
-        H.check(L.fcmf_embed_bwd(H.ptr(dz), H.ptr(ids), H.ptr(pos), H.ptr(tt), H.ptr(dword), H.ptr(dpos), H.ptr(dtt),
-                                 ntok, Hd, ctx.pad_id, H.dt(dz), H.stream()), "fcmf_embed_bwd")
+        two_d = ids.dim() == 2 and pos.is_contiguous()
+        H.check(L.fcmf_embed_bwd(H.ptr(dz), H.ptr(ids), H.ptr(pos), H.ptr(tt), H.ptr(dword), None if two_d else H.ptr(dpos),
+                                 H.ptr(dtt), ntok, Hd, ctx.pad_id, H.dt(dz), H.stream()), "fcmf_embed_bwd")
+        if two_d:      # [sequences, S] layout: position rows are shared by the offsets of all sequences
+            H.check(L.fcmf_embed_pos_bwd(H.ptr(dz), H.ptr(pos), H.ptr(dpos), ids.shape[0], ids.shape[1], Hd, ctx.pad_id,
+                                         H.dt(dz), H.stream()), "fcmf_embed_pos_bwd")
         return None, None, None, dword, dpos, dtt, dg, db, None, None, None, None, None
 
 
