@@ -207,6 +207,8 @@ int fcmf_xent_bwd(const void* logits, int64_t ld, const int64_t* labels, void* d
 /* ---------------------------------------------------------------------------------------
  * elementwise helpers */
 int fcmf_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* dst (bfloat16 [cols, rows]) = transpose(src float32 [rows, cols]): transposed weight copies for the dX GEMMs */
+int fcmf_cast_transpose(const float* src, void* dst, int rows, int cols, void* stream);
 /* y = x * dropout_mask(seed) / (1-p) ; used for the classifier-head dropout
  * (fcmf_multimodal.py:49) and its backward (same call on dy). */
 int fcmf_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);

@@ -59,6 +59,25 @@ __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD*
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) d[n4 * 4 + threadIdx.x] = from_f32<TD>(to_f32<TS>(s[n4 * 4 + threadIdx.x]));
 }
 
+// dst[c][r] = bf16(src[r][c]): 64x64 tiles through LDS, coalesced on both sides (transposed bf16 weight copies, so
+// that dX = dY * W reads W as a K-contiguous operand)
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int C) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty * 16 + i, c = c0 + tx;
+    tile[ty * 16 + i][tx] = (r < R && c < C) ? src[(int64_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty * 16 + i, r = r0 + tx;
+    if (c < C && r < R) dst[(int64_t)c * R + r] = (bf16_t)tile[tx][ty * 16 + i];
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p,
                                                       float inv_keep, uint64_t seed) {
@@ -235,6 +254,15 @@ extern "C" int fcmf_cast(const void* src, void* dst, int64_t n, int src_dtype, i
   else if (src_dtype == FCMF_F32 && dst_dtype == FCMF_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, n);
   else if (src_dtype == FCMF_BF16 && dst_dtype == FCMF_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
   else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_cast_transpose(const float* src, void* dst, int rows, int cols, void* stream) {
+  if (!src || !dst || rows < 0 || cols < 0) return FCMF_ERR_ARG;
+  if (rows == 0 || cols == 0) return FCMF_OK;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (bf16_t*)dst, rows, cols);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }

@@ -217,14 +217,14 @@ def _post_bwd(dy, c, saved, wo, w1, w2, g1, g2, p, seeds, G, side):
     co, c1, c2 = ops.as_compute(wo, dt), ops.as_compute(w1, dt), ops.as_compute(w2, dt)
     dz2, df = _ln_bwd(dy, z2, g2, m2, r2, p, seeds[1], G["g2"], G["be2"], G["b2"])
     du = torch.empty((M, I), dtype=dt, device=c.device)
-    ops.gemm(df, c2, du, M, I, Hd, Hd, I, I, 0, 1, aux=u, epi=H.EPI_DGELU, colsum=G["b1"])     # (df W2) * gelu'(u); db1
+    ops.gemm_dx(df, w2, c2, du, M, I, Hd, aux=u, epi=H.EPI_DGELU, colsum=G["b1"])               # (df W2) * gelu'(u); db1
     side.launch((df, a), df, a, G["w2"], Hd, I, M, Hd, I, I, 1, 1, acc=True)                   # dW2 = df^T a
     dh1 = torch.empty((M, Hd), dtype=dt, device=c.device)
-    ops.gemm(du, c1, dh1, M, Hd, I, I, Hd, Hd, 0, 1, aux=dz2, epi=H.EPI_ADD)                   # du W1 + dz2 (residual)
+    ops.gemm_dx(du, w1, c1, dh1, M, Hd, I, aux=dz2, epi=H.EPI_ADD)                             # du W1 + dz2 (residual)
     side.launch((du, h1), du, h1, G["w1"], I, Hd, M, I, Hd, Hd, 1, 1, acc=True)                # dW1 = du^T h1
     dz1, dh = _ln_bwd(dh1, z1, g1, m1, r1, p, seeds[0], G["g1"], G["be1"], G["bo"])
     dc = torch.empty((M, Hd), dtype=dt, device=c.device)
-    ops.gemm(dh, co, dc, M, Hd, Hd, Hd, Hd, Hd, 0, 1)
+    ops.gemm_dx(dh, wo, co, dc, M, Hd, Hd)
     side.launch((dh, c), dh, c, G["wo"], Hd, Hd, M, Hd, Hd, Hd, 1, 1, acc=True)
     return dc, dz1
 
@@ -306,7 +306,8 @@ class SelfLayerFn(torch.autograd.Function):
         dqkv = self_attention_bwd(qkv, mk, c, lse, dc, G_, T, Hd, heads, p_a, seed_a)
         wqkv = _fused_weight([wq, wk, wv], dt)
         dx = torch.empty((M, Hd), dtype=dt, device=x2.device)
-        ops.gemm(dqkv, wqkv, dx, M, Hd, 3 * Hd, 3 * Hd, Hd, Hd, 0, 1, aux=dz1, epi=H.EPI_ADD)   # + residual gradient
+        wm = _fused_weight([wq, wk, wv], torch.float32)
+        ops.gemm_dx(dqkv, wm if wm.data_ptr() == wq.data_ptr() else None, wqkv, dx, M, Hd, 3 * Hd, aux=dz1, epi=H.EPI_ADD)   # + residual gradient
         side.launch((dqkv, x2), dqkv, x2, G["wqkv"], 3 * Hd, Hd, M, 3 * Hd, Hd, Hd, 1, 1, acc=True)
         H.check(H.lib().fcmf_colsum(H.ptr(dqkv), H.ptr(G["bqkv"]), M, 3 * Hd, 3 * Hd, H.dt(dqkv), 1, H.stream()), "fcmf_colsum")
         side.join()

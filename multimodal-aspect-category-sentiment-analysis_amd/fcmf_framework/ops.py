@@ -58,6 +58,23 @@ class _Shadows:
     def __init__(self):
         self.map = {}
         self.pad = {}
+        self.mapT = {}
+
+    def get_t(self, w):
+        """bf16 TRANSPOSE [K, N] of a float32 [N, K] weight: dX = dY W then reads W^T as a K-contiguous operand
+        (ds_read_b128 instead of transposed LDS reads: the NT kernels run 10-25 % faster than the NN ones).
+        Rebuilt lazily after every optimizer step (one small kernel per weight)."""
+        key = (w.data_ptr(), tuple(w.shape))
+        ent = self.mapT.get(key)
+        if ent is not None and ent[1] == w._version and not ent[2]:
+            return ent[0]
+        sh = ent[0] if ent is not None else torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=w.device)
+        src = w.detach()
+        if not src.is_contiguous():
+            src = src.contiguous()
+        H.check(H.lib().fcmf_cast_transpose(H.ptr(src), H.ptr(sh), w.shape[0], w.shape[1], H.stream()), "fcmf_cast_transpose")
+        self.mapT[key] = [sh, w._version, False]
+        return sh
 
     def padded(self, w):
         """the fresh bf16 copy of a 2-D weight including its zero rows up to a multiple of 32"""
@@ -100,10 +117,13 @@ class _Shadows:
     def mark_all_stale(self):
         for ent in self.map.values():
             ent[2] = True
+        for ent in self.mapT.values():
+            ent[2] = True
 
     def clear(self):
         self.map.clear()
         self.pad.clear()
+        self.mapT.clear()
 
 
 shadows = _Shadows()
@@ -211,6 +231,16 @@ def _ld(x):
     return x.stride(0) if x.shape[0] > 1 else x.shape[1]
 
 
+def gemm_dx(dy, weight, w_compute, dx, M, K_in, N_out, aux=None, epi=H.EPI_NONE, colsum=None):
+    """dx [M,K_in] = dy [M,N_out] @ W [N_out,K_in] (+ epilogue).  bf16 mode multiplies by the transposed bf16 copy of the
+    float32 master `weight` (an NT GEMM); f32 mode, or a weight without a master, uses `w_compute` as it lies (NN)."""
+    if dy.dtype == torch.bfloat16 and weight is not None and weight.dtype == torch.float32 and weight.dim() == 2:
+        wt = shadows.get_t(weight)                                   # [K_in, N_out]
+        gemm(dy, wt, dx, M, K_in, N_out, N_out, N_out, K_in, 0, 0, aux=aux, epi=epi, colsum=colsum)
+    else:
+        gemm(dy, w_compute, dx, M, K_in, N_out, N_out, K_in, K_in, 0, 1, aux=aux, epi=epi, colsum=colsum)
+
+
 def _linear_fwd(x, w, bias, epi=H.EPI_NONE, aux=None):
     M, K = x.shape
     N = w.shape[0]
@@ -219,14 +249,15 @@ def _linear_fwd(x, w, bias, epi=H.EPI_NONE, aux=None):
     return y
 
 
-def _linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=True, dx_epi=H.EPI_NONE, dx_aux=None):
-    """x [M,K], w [N,K] (compute dtype), dy [M,N] -> dx [M,K], dW [N,K] f32, db [N] f32"""
+def _linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=True, dx_epi=H.EPI_NONE, dx_aux=None, master=None):
+    """x [M,K], w [N,K] (compute dtype), dy [M,N] -> dx [M,K], dW [N,K] f32, db [N] f32
+    (master = the float32 parameter behind w, if any: bf16 mode then uses its transposed copy for dx)"""
     M, K = x.shape
     N = w.shape[0]
     dx = dw = db = None
     if need_dx:
         dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
-        gemm(dy, w, dx, M, K, N, N, K, K, 0, 1, aux=dx_aux, epi=dx_epi)
+        gemm_dx(dy, master, w, dx, M, K, N, aux=dx_aux, epi=dx_epi)
     if need_dw:
         dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
         gemm(dy, x, dw, N, K, M, N, _ld(x), K, 1, 1, acc=True)
@@ -260,7 +291,7 @@ class LinearFn(torch.autograd.Function):
             dy2 = d
         w = as_compute(weight, x2.dtype)
         dx, dw, db = _linear_bwd(x2, w, dy2, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                 ctx.has_bias and ctx.needs_input_grad[2])
+                                 ctx.has_bias and ctx.needs_input_grad[2], master=weight)
         return (None if dx is None else dx.view(ctx.xshape)), dw, db, None
 
 
@@ -344,8 +375,8 @@ class FFNFn(torch.autograd.Function):
         x2, w1, w2, u, a = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         c1, c2 = as_compute(w1, x2.dtype), as_compute(w2, x2.dtype)
-        du, dw2, db2 = _linear_bwd(a, c2, dy2, True, True, True, dx_epi=H.EPI_DGELU, dx_aux=u)
-        dx, dw1, db1 = _linear_bwd(x2, c1, du, ctx.needs_input_grad[0], True, True)
+        du, dw2, db2 = _linear_bwd(a, c2, dy2, True, True, True, dx_epi=H.EPI_DGELU, dx_aux=u, master=w2)
+        dx, dw1, db1 = _linear_bwd(x2, c1, du, ctx.needs_input_grad[0], True, True, master=w1)
         return (None if dx is None else dx.view(ctx.xshape)), dw1, db1, dw2, db2
 
 
