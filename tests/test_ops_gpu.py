@@ -215,6 +215,42 @@ def test_vocab_linear_ragged_vocabulary_bf16(dev):
         ops.shadows.clear()
 
 
+def test_transposed_weight_shadow_follows_optimizer_steps(dev):
+    """bf16 dX GEMMs multiply by a cached transposed copy of the float32 master weight: it must be rebuilt after a
+    FusedAdamW step and after an in-place torch update (version counter)"""
+    ops, H = _ops()
+    from fcmf_framework.optimization import FusedAdamW
+    ops.set_compute_dtype(torch.bfloat16)
+    ops.shadows.clear()
+    try:
+        w = torch.nn.Parameter(_rand((96, 160), dev, seed=1) * 0.2)
+        x = _rand((300, 160), dev, torch.bfloat16, seed=2)
+        g = _rand((300, 96), dev, torch.bfloat16, seed=3)
+
+        def dx_of():
+            xi = x.clone().requires_grad_(True)
+            ops.linear(xi, w).backward(g)
+            return xi.grad.float().cpu()
+
+        def ref():
+            return g.float().cpu() @ w.detach().to(torch.bfloat16).float().cpu()
+
+        assert rel_err(dx_of(), ref()) < 2e-2
+        wt0 = ops.shadows.get_t(w).clone()
+        opt = FusedAdamW([w], lr=5e-2)
+        w.grad = torch.ones_like(w)
+        opt.step()
+        assert rel_err(dx_of(), ref()) < 2e-2
+        assert not torch.equal(ops.shadows.get_t(w), wt0)
+        with torch.no_grad():
+            w.mul_(-1.5)                      # in-place torch update: only the version counter tells
+        assert rel_err(dx_of(), ref()) < 2e-2
+        assert rel_err(ops.shadows.get_t(w).float().t(), w.detach().to(torch.bfloat16).float()) < 1e-6
+    finally:
+        ops.set_compute_dtype(torch.float32)
+        ops.shadows.clear()
+
+
 def test_colsum(dev):
     ops, H = _ops()
     for dtype in (torch.float32, torch.bfloat16):
