@@ -826,218 +826,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 }
 
 // =========================================================================================
-// 256x256 kernel with FOUR waves (2 x 2), every wave a 128x128 output tile: 64 accumulator fragments
-// (256 registers of the 512 a wave owns at one wave per SIMD) fed by 16 fragment reads per k-tile -- half the
-// LDS read instructions per MFMA of the 8-wave kernel, which is what the weight-gradient GEMMs (both operands
-// through ds_read_b64_tr_b16, two reads per fragment) are bound by.  Fragments are double-buffered in
-// registers: the reads of k-tile t+1 are issued under the 64 MFMAs of k-tile t.  f32 outputs only
-// (accumulate / split-K through the workspace or float atomics), same persistent item walk and LDS-DMA ring.
-// =========================================================================================
-__device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x8& b) {
-  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-
-template <bool A_TR, bool B_TR>
-__device__ __forceinline__ void gemm_bf16_w4_body(const GemmParams& p) {
-  constexpr int NW = 4, PT = 8;                // waves; DMAs per k-tile per wave (4 A + 4 B pieces)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;     // rows wm*128, cols wn*128
-  const int tiles_n = (p.N + GB - 1) / GB;
-  const int nblk = gridDim.x;
-  int slot = blockIdx.x;
-  {
-    int q = nblk >> 3, r = nblk & 7, xcd = slot & 7, local = slot >> 3;
-    slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  }
-  const int nk_total = (p.K + BK - 1) / BK;
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
-  const unsigned a_step = A_TR ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
-  const unsigned b_step = B_TR ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
-  typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
-  const int rowl = lane & 15, g4 = lane >> 4, q4 = rowl >> 2, p4 = rowl & 3;
-  const int row_base = rowl * 64 + ((g4 ^ swz_row(rowl)) << 4);
-  const int trk = tr_key(8 * g4 + q4);
-  const int tr_col = ((p4 >> 1) << 4) + ((p4 & 1) << 3);
-  const int a_lane = A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * 128 * 64;
-  const int b_lane = A_TILE_BYTES + (B_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wn * 128 * 64);
-  auto frag = [&](const char* st, int lane_off, bool tr, int blk) -> bf16x8 {   // blk = 16-wide block index inside the tile
-    if (!tr) return *reinterpret_cast<const bf16x8*>(st + lane_off + (blk & 7) * 1024);
-    const char* q = st + lane_off + ((blk ^ trk) << 5);
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * 512));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-  };
-  struct Item { int i0, j0, kt_begin, nkt, zsplit; };
-  auto decode = [&](int item) -> Item {
-    const int zsplit = item / p.tiles, tile = item - zsplit * p.tiles;
-    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
-    const int kb = zsplit * p.ktiles_per_split;
-    return Item{tile_m * GB, tile_n * GB, kb, min(nk_total, kb + p.ktiles_per_split) - kb, zsplit};
-  };
-  auto stage_at = [&](int s) { return smem + (s & (TNST - 1)) * TSTAGE_BYTES; };
-  auto lds_barrier = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
-  for (int item = slot; item < p.total_items; item += nblk) {
-  const Item w = decode(item);
-  const int i0 = w.i0, j0 = w.j0, nkt = w.nkt;
-  unsigned va[4], vb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    va[j] = dma_voffset_t<A_TR>(wave * 4 + j, lane, p.lda, i0, p.M);
-    vb[j] = dma_voffset_t<B_TR>(wave * 4 + j, lane, p.ldb, j0, p.N);
-    asm volatile("" : "+v"(va[j]), "+v"(vb[j]));
-  }
-  auto issue = [&](int t) {
-    char* st = stage_at(t);
-    const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      char* d = st + (wave * 4 + j) * 1024;
-      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va[j] + ka, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, va[j], ka, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      char* d = st + A_TILE_BYTES + (wave * 4 + j) * 1024;
-      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb[j] + kb, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, vb[j], kb, 0, 0);
-    }
-  };
-  // tile t landed (own DMAs) once at most the younger tiles issued so far (PT DMAs each) are outstanding
-  auto wait_landed = [&](int t, int issued_upto) {
-    int younger = min(nkt - 1, issued_upto) - t;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  f32x4 acc[8][8];  // [j frag][i frag]
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa[2][8], fb[2][8];
-  auto load_frags = [&](auto set, int t) {
-    constexpr int S = decltype(set)::value;
-    const char* st = stage_at(t);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      fb[S][f] = frag(st, b_lane, B_TR, wn * 8 + f);
-      fa[S][f] = frag(st, a_lane, A_TR, wm * 8 + f);
-    }
-  };
-  auto mma = [&](auto set) {
-    constexpr int S = decltype(set)::value;
-#pragma unroll
-    for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-      for (int fj = 0; fj < 8; ++fj)
-        // (accumulators pinned to the AGPR half of the register file: left to itself the compiler shuttles them
-        // through v_accvgpr_read/write around every MFMA)
-        mfma_agpr(acc[fj][fi], fb[S][fj], fa[S][fi]);
-  };
-  // k-tile t: its fragments sit in register set S; the reads of tile t+1 go into the other set under the MFMAs
-  auto step = [&](auto set, auto other, int t) {
-    if (t + 1 < nkt) {
-      wait_landed(t + 1, t + 3);
-      __builtin_amdgcn_s_barrier();          // tile t+1 visible to every wave; every wave has read tile t out of LDS
-      if (t + 4 < nkt) issue(t + 4);         // into the stage of tile t
-      load_frags(other, t + 1);
-    }
-    mma(set);
-  };
-
-  issue(0);
-  if (1 < nkt) issue(1);
-  if (2 < nkt) issue(2);
-  if (3 < nkt) issue(3);
-  wait_landed(0, 3);
-  __builtin_amdgcn_s_barrier();
-  load_frags(IntTag<0>{}, 0);
-  for (int t = 0; t < nkt; t += 2) {
-    step(IntTag<0>{}, IntTag<1>{}, t);
-    if (t + 1 < nkt) step(IntTag<1>{}, IntTag<0>{}, t + 1);
-  }
-
-  // ---- f32 epilogue: accumulators -> LDS (f32, one 128-row half at a time, the whole ring) -> rows
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the inline-asm MFMAs are opaque to the hazard recogniser: let the last one retire
-  {
-    constexpr int LPR = GB / 8, RPI = 64 / LPR, RPW = 128 / NW;     // 32 lanes per row, 2 rows per instruction, 32 rows per wave
-    const bool to_ws = p.ws != nullptr && p.ksplit > 1;
-    const bool atomic = (p.ksplit > 1) && !to_ws;
-    const bool lead = (w.zsplit == 0);
-    float* Cout = to_ws ? p.ws + (int64_t)w.zsplit * p.M * p.N : reinterpret_cast<float*>(p.C);
-    const int64_t ldo = to_ws ? (int64_t)p.N : p.ldc;
-    const bool rmw = p.accumulate && !to_ws;
-    float* Ct = reinterpret_cast<float*>(smem);   // [128][256] f32; 16-B chunk index XOR (row & 7)
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int c0 = (lane_e % LPR) * 2, gj = j0 + c0 * 4, rsub = lane_e / LPR;
-    lds_barrier();                                // every wave is done with the operand ring
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      if (wm == half) {
-#pragma unroll
-        for (int fi = 0; fi < 8; ++fi) {
-          const int row = fi * 16 + (lane_e & 15);
-#pragma unroll
-          for (int fj = 0; fj < 8; ++fj) {
-            const int chunk = wn * 32 + fj * 4 + (lane_e >> 4);
-            *reinterpret_cast<f32x4*>(Ct + row * GB + ((chunk ^ (row & 7)) << 2)) = acc[fj][fi];
-          }
-        }
-      }
-      lds_barrier();
-      if (atomic) {
-        float* Cf = reinterpret_cast<float*>(p.C);
-        for (int it = 0; it < RPW; ++it) {
-          const int row = wave * RPW + it, gi = i0 + half * 128 + row;
-          if (gi >= p.M) continue;
-#pragma unroll
-          for (int k = 0; k < GB / 64; ++k) {
-            const int col = lane_e + 64 * k, gjc = j0 + col;
-            if (gjc < p.N) atomicAdd(Cf + (int64_t)gi * p.ldc + gjc, Ct[row * GB + ((((col >> 2)) ^ (row & 7)) << 2) + (col & 3)]);
-          }
-        }
-      } else {
-        f32x2 bv[4] = {splat2(0.f), splat2(0.f), splat2(0.f), splat2(0.f)};
-        if (p.bias && lead && gj < p.N) load8f(p.bias + gj, bv);
-#pragma unroll 2
-        for (int it = 0; it < RPW / RPI; ++it) {
-          const int row = wave * RPW + it * RPI + rsub, gi = i0 + half * 128 + row;
-          if (gi >= p.M || gj >= p.N) continue;
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(Ct + row * GB + ((c0 ^ (row & 7)) << 2));
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(Ct + row * GB + (((c0 + 1) ^ (row & 7)) << 2));
-          f32x2 v[4] = {f32x2{lo[0], lo[1]} + bv[0], f32x2{lo[2], lo[3]} + bv[1], f32x2{hi[0], hi[1]} + bv[2], f32x2{hi[2], hi[3]} + bv[3]};
-          float* cf = Cout + (int64_t)gi * ldo + gj;
-          if (rmw) {
-            f32x2 o[4];
-            load8f(cf, o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] + o[e];
-          }
-          store8f(cf, v);
-        }
-      }
-      lds_barrier();
-    }
-  }
-  }  // work items
-}
-
-template <bool A_TR, bool B_TR>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmParams p) {
-  gemm_bf16_w4_body<A_TR, B_TR>(p);
-}
-
-// =========================================================================================
 // generic kernel: C = op(A) op(B) with arbitrary element strides, f32 MFMA (exact fmaf chains)
 // =========================================================================================
 struct GenericParams {
@@ -1290,7 +1078,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     bool large = tile_ok && M >= 256 && N >= 256 &&
                  ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && K >= 1024));
     if (g_force_tile == 128) large = false;
-    if (g_force_tile == 256 || g_force_tile == 192 || g_force_tile == 1256) large = tile_ok;
+    if (g_force_tile == 256 || g_force_tile == 192) large = tile_ok;
     if (large) {
       const int slots = g_num_cus;
       // block tile rows: 256, or 192 where that removes a nearly empty last round (cost model: rounds x
@@ -1328,23 +1116,6 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
         else snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile256_kernel<%d,%d,%s,%s>", trans_a, trans_b, out_dtype == FCMF_F32 ? "f32" : "bf16", epi_names[epilogue]);
       }
       int rc;
-      const bool w4 = g_force_tile == 1256 && out_dtype == FCMF_F32 && epilogue == FCMF_EPI_NONE && !colsum;
-      if (w4) {
-        const size_t smem = (size_t)TNST * TSTAGE_BYTES;
-        snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_w4_kernel<%d,%d>", trans_a, trans_b);
-#define FCMF_W4(TA, TB)                                                                                                   \
-  do {                                                                                                                    \
-    auto k = gemm_bf16_w4_kernel<TA, TB>;                                                                                 \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, p);                                                                  \
-  } while (0)
-        if (!trans_a && !trans_b) FCMF_W4(false, false);
-        else if (!trans_a && trans_b) FCMF_W4(false, true);
-        else if (trans_a && !trans_b) FCMF_W4(true, false);
-        else FCMF_W4(true, true);
-#undef FCMF_W4
-        rc = FCMF_OK;
-      } else
       if (!trans_a && !trans_b) rc = launch_bf16_tile<false, false>(p, out_dtype, grid, st, tm);
       else if (!trans_a && trans_b) rc = launch_bf16_tile<false, true>(p, out_dtype, grid, st, tm);
       else if (trans_a && !trans_b) rc = launch_bf16_tile<true, false>(p, out_dtype, grid, st, tm);
