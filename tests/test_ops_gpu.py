@@ -417,6 +417,8 @@ def test_embedding_layer_norm(dev, dtype):
     ids = torch.randint(3, V, (B, S), generator=torch.Generator().manual_seed(1))
     ids[0, 7:] = pad
     ids[2, 3:] = pad
+    ids[3, 0] = pad        # a leading pad: this sequence's position ids lag the others' at every offset (the
+    ids[1, 5] = pad        # per-token fallback of the position-gradient kernel), an interior pad likewise
     word, ptab, ttab = (_rand(s, dev, seed=i).requires_grad_(True) for i, s in enumerate(((V, H_), (Pn, H_), (2, H_))))
     g = (1 + 0.1 * _rand((H_,), dev, seed=7)).requires_grad_(True)
     b = _rand((H_,), dev, seed=8).requires_grad_(True)
