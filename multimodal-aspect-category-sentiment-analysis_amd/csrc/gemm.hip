@@ -9,6 +9,7 @@
 //                        shapes (classifier N=4, box WG 64->8 ...).
 #include "common.h"
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -1032,7 +1033,13 @@ extern "C" int fcmf_gemm_set_workspace(void* ptr, int64_t bytes, void* stream) {
   return FCMF_OK;
 }
 
-static int g_num_cus = 256;    // MI355X: 8 XCDs x 32 CUs; one persistent 128-KiB-LDS workgroup per CU
+// MI355X: 8 XCDs x 32 CUs; one persistent 160-KiB-LDS workgroup per CU.  FCMF_GEMM_CUS=<n> (read once) makes the
+// persistent GEMMs use n workgroups, leaving CUs to kernels that run beside them (RCCL in data-parallel runs).
+static int g_num_cus = [] {
+  const char* e = getenv("FCMF_GEMM_CUS");
+  const int n = e ? atoi(e) : 256;
+  return n >= 8 && n <= 256 ? n : 256;
+}();
 // name of the kernel the last fcmf_gemm call of this thread dispatched (benchmarks attribute time by it)
 static thread_local char g_last_kernel[96] = "";
 extern "C" const char* fcmf_gemm_last_kernel(void) { return g_last_kernel; }
