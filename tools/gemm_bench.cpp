@@ -1,5 +1,5 @@
 // Standalone GEMM micro-benchmark over the FCMF step's shapes (links libfcmf_hip.so).
-//   hipcc -O2 tools/gemm_bench.cpp -Iinclude -L<pkg>/fcmf_framework -lfcmf_hip -o tools/bin/gemm_bench   (tools/bin/ travels to the GPU box, gpurun_out/ does not)
+//   hipcc -O2 --offload-arch=gfx950 tools/gemm_bench.cpp -Iinclude -L<pkg>/fcmf_framework -lfcmf_hip -o tools/bin/gemm_bench   (tools/bin/ travels to the GPU box, gpurun_out/ does not)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -7,6 +7,15 @@
 #include <vector>
 #include <dlfcn.h>
 #include "fcmf_hip.h"
+
+// a stand-in for a communication kernel: `blocks` workgroups that each hold a CU's LDS (so no persistent GEMM
+// workgroup fits beside them) and spin for `ticks` of the 100 MHz counter
+__global__ void hog_kernel(unsigned long long ticks) {
+  extern __shared__ char hog_lds[];
+  hog_lds[threadIdx.x] = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 
 struct Shape { const char* name; int M, N, K, ta, tb, epi, acc, out_f32; };
 
@@ -69,6 +78,9 @@ int main(int argc, char** argv) {
     hipMalloc(&ws, wsb);
     fcmf_gemm_set_workspace(ws, (int64_t)wsb, nullptr);
   }
+  const int hog = getenv("FCMF_BENCH_HOG") ? atoi(getenv("FCMF_BENCH_HOG")) : 0;   // CUs taken away by a co-running kernel
+  hipStream_t hs; hipStreamCreate(&hs);
+  if (hog) hipFuncSetAttribute((const void*)hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (auto& sh : shapes) {
     int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.N : sh.K, ldc = sh.N;
@@ -78,12 +90,18 @@ int main(int argc, char** argv) {
     };
     int rc = run(); rc |= run();
     hipDeviceSynchronize();
+    if (hog) {   // the hog outlives the timed launches (it needs the CUs' LDS: a resident persistent GEMM workgroup excludes it and vice versa)
+      hipLaunchKernelGGL(hog_kernel, dim3(hog), dim3(256), 64 * 1024, hs, (unsigned long long)(100000ull * 30));   // 30 ms
+      hipStreamQuery(hs);
+      for (volatile int spin = 0; spin < 2000000; ++spin) {}
+    }
     hipEventRecord(e0, nullptr);
     for (int i = 0; i < reps; ++i) run();
     hipEventRecord(e1, nullptr);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
+    if (hog) hipStreamSynchronize(hs);
     double tf = 2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12;
     printf("%-40s rc=%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 2500)\n", sh.name, rc, ms, tf, tf / 25.0);
     // diagnostic library (make timing; LD_LIBRARY_PATH=tools/bin/timing): per-phase stamps of workgroup 0
