@@ -1,5 +1,9 @@
+"""Test infrastructure (not collected by pytest): times the CPU oracle at several thread counts on the GPU box's host
+to pick the thread count of bench.py's cpu_baseline leg (16 was fastest: the box exposes 256 logical CPUs but a
+16-core share).  Usage: python tests/oracle_thread_scan.py"""
 import sys, time, os, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/multimodal-aspect-category-sentiment-analysis_amd')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'multimodal-aspect-category-sentiment-analysis_amd'))
 import synthetic_data as synth
 from oracle import fcmf_oracle as O
 cfg, NI, NR = synth.BASE_CFG, 7, 36
