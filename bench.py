@@ -71,7 +71,7 @@ def cpu_baseline(threads_note):
     import synthetic_data as synth
     from oracle import fcmf_oracle as O
     # 16 threads = the CPU share of a one-GPU box on this pool and the fastest setting measured on it
-    # (tools/cpu_thread_scan.py: 16 -> 0.53, 32 -> 0.35, 64 -> 0.16, 128 -> 0.04 samples/s fwd+bwd)
+    # (tests/oracle_thread_scan.py: 16 -> 0.53, 32 -> 0.35, 64 -> 0.16, 128 -> 0.04 samples/s fwd+bwd)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     cfg, NI, NR, B = synth.BASE_CFG, 7, 36, 4
     P = {k: v.requires_grad_(True) for k, v in synth.synth_params(synth.fcmf_param_shapes(cfg)).items()}
