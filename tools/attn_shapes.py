@@ -11,5 +11,5 @@ def fwd(ctx, q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, ca
         seen.add(key); print("ATTN", key, flush=True)
     return orig(ctx, q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal)
 pkg.AttentionFn.forward = staticmethod(fwd)
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "0"]
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
 bench.main()
