@@ -109,6 +109,11 @@ def main():
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world:
+        # one process per GPU: ranks come from the launcher (torch.distributed.run sets WORLD_SIZE); a bare
+        # `python bench.py --gpus 8` would silently measure one GPU
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with `python -m torch.distributed.run "
+                 f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
     local = int(os.environ.get("LOCAL_RANK", 0))
     if os.environ.get("FCMF_BENCH_SINGLE_DEVICE"):   # rehearsal: several ranks share cuda:0 (use with --backend gloo)
         local = 0

@@ -1024,12 +1024,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // caller-owned split-K workspaces, one per stream (a GEMM on a stream without one uses float atomics)
 struct Workspace { float* ptr; int64_t bytes; };
+struct WsKey {
+  int device; void* stream;
+  bool operator==(const WsKey& o) const { return device == o.device && stream == o.stream; }
+};
+struct WsKeyHash {
+  size_t operator()(const WsKey& k) const { return std::hash<void*>()(k.stream) ^ (std::hash<int>()(k.device) * 0x9E3779B97F4A7C15ull); }
+};
 static std::mutex g_ws_mutex;
-static std::unordered_map<void*, Workspace> g_ws;
+static std::unordered_map<WsKey, Workspace, WsKeyHash> g_ws;   // keyed by (current device, stream): stream 0 exists on every device
+static WsKey ws_key(void* stream) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return WsKey{dev, stream};
+}
 extern "C" int fcmf_gemm_set_workspace(void* ptr, int64_t bytes, void* stream) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
-  if (!ptr || bytes <= 0) g_ws.erase(stream);
-  else g_ws[stream] = Workspace{reinterpret_cast<float*>(ptr), bytes};
+  if (!ptr || bytes <= 0) g_ws.erase(ws_key(stream));
+  else g_ws[ws_key(stream)] = Workspace{reinterpret_cast<float*>(ptr), bytes};
   return FCMF_OK;
 }
 
@@ -1114,7 +1126,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       p.ws = nullptr;
       if (p.ksplit > 1) {
         std::lock_guard<std::mutex> lock(g_ws_mutex);
-        auto it = g_ws.find(stream);
+        auto it = g_ws.find(ws_key(stream));
         if (it != g_ws.end() && it->second.bytes >= (int64_t)p.ksplit * M * N * 4) p.ws = it->second.ptr;
       }
       {

@@ -93,11 +93,9 @@ class Attention(nn.Module):
                 causal = True
             else:
                 raise NotImplementedError("1-D memory_len (key-length fill mask) is only used by the disabled MDE")
-        nh, E, hd = self.w_kx.shape
-        wk = self.w_kx.permute(0, 2, 1).reshape(nh * hd, E)   # nn.Linear layout [out, in], natural head order
-        wq = self.w_qx.permute(0, 2, 1).reshape(nh * hd, E)
-        kx = ops.linear(k, wk)
-        qx = ops.linear(q, wq)
+        nh = self.n_head
+        kx = ops.head_linear(k, self.w_kx)        # [.., nh*hd], natural head order
+        qx = ops.head_linear(q, self.w_qx)
         out = _QuirkAttentionFn.apply(qx, kx, nh, causal)
         self.attention_weights = None  # probabilities are never materialised by the fused kernel
         return ops.linear(out, self.proj.weight, self.proj.bias), None

@@ -59,6 +59,7 @@ class _Shadows:
         self.map = {}
         self.pad = {}
         self.mapT = {}
+        self.mapD = {}
 
     def get_t(self, w):
         """bf16 TRANSPOSE [K, N] of a float32 [N, K] weight: dX = dY W then reads W^T as a K-contiguous operand
@@ -104,6 +105,18 @@ class _Shadows:
         self.map[key] = [sh, w._version, False]
         return sh
 
+    def derived(self, w, tag, build):
+        """a tensor derived from the PARAMETER `w` (a re-layout and / or cast), cached per (storage, shape, tag) and
+        rebuilt by `build(w.detach())` when the parameter has changed.  Only ever key this on persistent leaf
+        parameters: a temporary's address is recycled by the caching allocator (and its version is always 0)."""
+        key = (w.data_ptr(), tuple(w.shape), tag)
+        ent = self.mapD.get(key)
+        if ent is not None and ent[1] == w._version and not ent[2]:
+            return ent[0]
+        t = build(w.detach())
+        self.mapD[key] = [t, w._version, False]
+        return t
+
     def peek(self, w):
         ent = self.map.get((w.data_ptr(), tuple(w.shape)))
         return None if ent is None else ent[0]
@@ -119,11 +132,14 @@ class _Shadows:
             ent[2] = True
         for ent in self.mapT.values():
             ent[2] = True
+        for ent in self.mapD.values():
+            ent[2] = True
 
     def clear(self):
         self.map.clear()
         self.pad.clear()
         self.mapT.clear()
+        self.mapD.clear()
 
 
 shadows = _Shadows()
@@ -297,6 +313,56 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, weight, bias=None, act=None):
     return LinearFn.apply(x, weight, bias, act)
+
+
+class HeadLinearFn(torch.autograd.Function):
+    """y[..., h*d + j] = sum_e x[..., e] * w[h, e, j]: the per-head projections of the IAOG decoder `Attention`
+    (w_kx / w_qx [n_head, E, d], mm_modeling.py:57-58,79-92) as ONE GEMM against the [n_head*d, E] re-layout of the
+    parameter instead of the reference's B-fold `repeat` + bmm.  The re-layouts (and their bf16 casts) are cached
+    on the PARAMETER (`shadows.derived`), never on a temporary."""
+
+    @staticmethod
+    def _layouts(w, dtype):
+        nh, E, d = w.shape
+
+        def nk(src):      # [n_head*d, E]: nn.Linear layout, natural head order
+            return cast(src.permute(0, 2, 1).reshape(nh * d, E), dtype)
+
+        def kn(src):      # [E, n_head*d]: its transpose, the K-contiguous operand of dx = dy W
+            return cast(src.permute(1, 0, 2).reshape(E, nh * d), dtype)
+        return shadows.derived(w, ("head_nk", dtype), nk), (lambda: shadows.derived(w, ("head_kn", dtype), kn))
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x2 = _rows(x)
+        nh, E, d = w.shape
+        wl, _ = HeadLinearFn._layouts(w, x2.dtype)
+        y = _linear_fwd(x2, wl, None)
+        ctx.save_for_backward(x2, w)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], nh * d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        nh, E, d = w.shape
+        M, N = x2.shape[0], nh * d
+        dy2 = dy.reshape(-1, N).contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            _, kn = HeadLinearFn._layouts(w, x2.dtype)
+            dx = torch.empty((M, E), dtype=dy2.dtype, device=dy2.device)
+            gemm(dy2, kn(), dx, M, E, N, N, N, E, 0, 0)                      # NT: both operands K-contiguous
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dwl = torch.zeros((N, E), dtype=torch.float32, device=dy2.device)
+            gemm(dy2, x2, dwl, N, E, M, N, _ld(x2), E, 1, 1, acc=True)       # [n_head*d, E] = dy^T x
+            dw = dwl.view(nh, d, E).permute(0, 2, 1)                         # the parameter's [n_head, E, d] layout
+        return dx, dw
+
+
+def head_linear(x, w):
+    return HeadLinearFn.apply(x, w)
 
 
 class VocabLinearFn(torch.autograd.Function):

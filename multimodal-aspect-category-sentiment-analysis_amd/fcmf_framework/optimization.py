@@ -158,7 +158,17 @@ class FusedAdamW(Optimizer):
             sizes=i64(sizes),
             group=torch.tensor([g for _, g in plist], dtype=torch.int32, device=device),
             ct=torch.tensor(ct, dtype=torch.int32, device=device), co=i64(co), nchunks=len(ct),
-            pptr=[p.data_ptr() for p, _ in plist])
+            pptr=[p.data_ptr() for p, _ in plist],
+            mvptr=[(self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()) for p, _ in plist])
+
+    def load_state_dict(self, state_dict):
+        """accepts a FusedAdamW checkpoint or one written by the reference's torch.optim.AdamW
+        (run_multimodal_fcmf.py:289,389-391): same per-parameter keys; torch stores `step` as a tensor"""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if 'step' in st and torch.is_tensor(st['step']):
+                st['step'] = int(st['step'].item())
+        self._tables = None        # the moment tensors were replaced: the cached device pointer tables are stale
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm=None):
@@ -177,7 +187,9 @@ class FusedAdamW(Optimizer):
             if not p.is_contiguous() or not p.grad.is_contiguous():
                 raise H.HipLibraryError("FusedAdamW expects contiguous parameters and gradients")
         T = self._tables
-        if T is None or T['key'] != tuple(id(p) for p, _ in plist) or T['pptr'] != [p.data_ptr() for p, _ in plist]:
+        if (T is None or T['key'] != tuple(id(p) for p, _ in plist) or T['pptr'] != [p.data_ptr() for p, _ in plist]
+                or T['mvptr'] != [(self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr())
+                                  if len(self.state[p]) else None for p, _ in plist]):
             self._build(plist, device)
             T = self._tables
         g_ptrs = torch.tensor([p.grad.data_ptr() for p, _ in plist], dtype=torch.int64).to(device, non_blocking=True)
@@ -194,7 +206,7 @@ class FusedAdamW(Optimizer):
                                        self.CHUNK, H.ptr(self._sumsq), 0, st), "fcmf_multi_sumsq")
             mg = float(max_grad_norm)
             self.last_grad_norm = self._sumsq  # sqrt taken lazily by grad_norm()
-        steps = {self.state[p]['step'] for p, _ in plist}
+        steps = {int(self.state[p]['step']) for p, _ in plist}
         if len(steps) != 1:
             raise H.HipLibraryError("FusedAdamW: parameters with different step counts are not supported")
         step = steps.pop() + 1

@@ -16,15 +16,29 @@ import warnings
 import numpy as np
 import torch
 
+import importlib.util
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+PKG = os.path.join(ROOT, "multimodal-aspect-category-sentiment-analysis_amd")
+REF = "/root/reference"
+# The reference's fcmf_framework has no __init__.py (a namespace package); the product's is a regular package and
+# would win whatever the sys.path order.  So the product directory never goes on sys.path here: the data generator
+# (no model arithmetic) is loaded by file path, and the import below is checked to resolve into /root/reference.
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != PKG]
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "multimodal-aspect-category-sentiment-analysis_amd"))
-sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REF)
 warnings.filterwarnings("ignore")
 
+import fcmf_framework  # noqa: E402
+assert list(fcmf_framework.__path__)[0].startswith(REF), \
+    f"fcmf_framework resolved to {list(fcmf_framework.__path__)}: the fixtures must come from the reference"
+_spec = importlib.util.spec_from_file_location("synthetic_data", os.path.join(PKG, "synthetic_data.py"))
+synth = importlib.util.module_from_spec(_spec)
+sys.modules["synthetic_data"] = synth
+_spec.loader.exec_module(synth)
+
 from oracle import fcmf_oracle as O  # noqa: E402
-import synthetic_data as synth  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
@@ -244,46 +258,121 @@ def bertadam_fixture():
     print("bertadam fixture ok")
 
 
+IAOG_SAMPLED = [
+    "decoder.blks.block0.attention1.w_kx", "decoder.blks.block0.attention1.w_qx",
+    "decoder.blks.block1.attention2.w_kx", "decoder.blks.block1.attention2.w_qx",
+    "decoder.blks.block0.attention2.proj.weight", "decoder.blks.block1.attention1.proj.bias",
+    "decoder.blks.block0.ffn.dense1.weight", "decoder.blks.block1.ffn.dense2.bias",
+    "decoder.blks.block0.addnorm1.ln.weight", "decoder.blks.block1.add_norm3.ln.bias",
+    "decoder.embedding.weight", "decoder.dense.bias",
+    "encoder.bert.cell.embeddings.word_embeddings.weight",     # tied: embedding lookups + vocabulary projection
+    "encoder.mm_attention.layer.0.output.dense.weight", "encoder.box_head.WGs.3.weight"]
+
+
 def iaog_fixture():
+    """IAOG pre-training step (run_pretraining_fcmf.py:186-189,208-212,309-337) at TWO batch sizes: the slot->head
+    pairing of the decoder `Attention` depends on B mod n_head (mm_modeling.py:79-85), so B=3 and B=4 (n_head=4)
+    exercise different pairings.  Stored per batch size: logits (every 8th column), loss, gradient norms of every
+    parameter, sampled gradient elements, the clip norm, and the post-AdamW(wd 1e-5 / 0, lr 3e-5) deltas."""
     cfg = synth.TINY_CFG
     patch_constants(cfg)
     from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq
-    hf = make_hf_dir(cfg)
     V = cfg["vocab_size"]
-    NI, NR, B, S, Ld = 2, 5, 3, 16, 6
-    model = FCMFSeq2Seq(V, 20, hf, NI, NR, 1.0)
-    # run_pretraining_fcmf.py:189 -- decoder.embedding is re-created (un-tied) by the driver
-    model.decoder.embedding = torch.nn.Embedding(V, model.decoder.num_hiddens)
-    shapes = synth.fcmf_param_shapes(cfg)
-    shapes = {k: v for k, v in shapes.items() if k.startswith("encoder.")}
-    shapes.update(synth.iaog_decoder_param_shapes(cfg, V))
-    P, extra = load_synth_into(model, shapes)
-    print("iaog unmapped keys:", extra)
-    model.eval()
-    batch = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, seed=5, coord_dtype=torch.float32)
-    rng = np.random.Generator(np.random.PCG64(9))
-    dec = torch.from_numpy(rng.integers(3, V, size=(B, Ld)))
-    labels = torch.roll(dec, -1, dims=1).clone()
-    labels[:, -1] = -100
-    logits = model(batch["input_ids"][:, 0], dec, batch["visual_embeds_att"], batch["roi_embeds_att"],
-                   batch["roi_coors"], batch["token_type_ids"][:, 0], batch["attention_mask"][:, 0],
-                   batch["added_attention_mask"][:, 0], None, is_train=True)
-    loss = torch.nn.CrossEntropyLoss(ignore_index=-100)(logits.permute(0, 2, 1), labels)
-    cross_w = model.decoder.blks.block0.attention2.attention_weights.detach()
-    # oracle pin
-    Pw = dict(P)
-    Pw["decoder.dense.weight"] = P["encoder.bert.cell.embeddings.word_embeddings.weight"]
-    enc = O.fcmf_encoder_forward(Pw, cfg, batch["input_ids"][:, 0], batch["visual_embeds_att"],
-                                 batch["roi_embeds_att"], batch["roi_coors"], batch["token_type_ids"][:, 0],
-                                 batch["attention_mask"][:, 0], batch["added_attention_mask"][:, 0], NI, NR)
-    ol = O.iaog_decoder_forward(Pw, cfg, dec, enc)
-    err = (ol - logits).abs().max().item()
-    print("iaog oracle-vs-reference logits", err, "loss", float(loss))
-    assert err < 1e-4
-    np.savez_compressed(os.path.join(GOLD, "iaog_tiny.npz"), dec=dec.numpy(), labels=labels.numpy(),
-                        logits=logits.detach().numpy()[:, :, ::8], loss=np.float32(loss.item()),
-                        cross_attn_nonzero=(cross_w[0] > 1e-30).sum(-1).numpy())
-    print("iaog fixture ok")
+    NI, NR, S, Ld = 2, 5, 16, 6
+    out = {}
+    for B in (3, 4):
+        hf = make_hf_dir(cfg)
+        model = FCMFSeq2Seq(V, 20, hf, NI, NR, 1.0)
+        # run_pretraining_fcmf.py:189 -- decoder.embedding is re-created (un-tied) by the driver
+        model.decoder.embedding = torch.nn.Embedding(V, model.decoder.num_hiddens)
+        shapes = synth.fcmf_param_shapes(cfg)
+        shapes = {k: v for k, v in shapes.items() if k.startswith("encoder.")}
+        shapes.update(synth.iaog_decoder_param_shapes(cfg, V))
+        P, extra = load_synth_into(model, shapes)
+        print("iaog unmapped keys:", extra)
+        model.eval()
+        batch = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, seed=5, coord_dtype=torch.float32)
+        rng = np.random.Generator(np.random.PCG64(9 + B))
+        dec = torch.from_numpy(rng.integers(3, V, size=(B, Ld)))
+        labels = torch.roll(dec, -1, dims=1).clone()
+        labels[:, -1] = -100
+        labels[B - 1, Ld - 3:] = -100        # one sequence with trailing pads (iaog_dataset.py:93-96)
+        model.zero_grad()
+        logits = model(batch["input_ids"][:, 0], dec, batch["visual_embeds_att"], batch["roi_embeds_att"],
+                       batch["roi_coors"], batch["token_type_ids"][:, 0], batch["attention_mask"][:, 0],
+                       batch["added_attention_mask"][:, 0], None, is_train=True)
+        loss = torch.nn.CrossEntropyLoss(ignore_index=-100)(logits.permute(0, 2, 1), labels)
+        cross_w = model.decoder.blks.block0.attention2.attention_weights.detach()
+        loss.backward()
+        named = dict(model.named_parameters())          # tied decoder.dense.weight is reported once (encoder name)
+        grads = {n: p.grad.detach().clone() for n, p in named.items() if p.grad is not None}
+        nograd = [n for n, p in named.items() if p.grad is None]
+
+        # ---- oracle pin: forward AND backward ------------------------------------------------
+        Pw = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        Pw["decoder.dense.weight"] = Pw["encoder.bert.cell.embeddings.word_embeddings.weight"]
+        enc = O.fcmf_encoder_forward(Pw, cfg, batch["input_ids"][:, 0], batch["visual_embeds_att"],
+                                     batch["roi_embeds_att"], batch["roi_coors"], batch["token_type_ids"][:, 0],
+                                     batch["attention_mask"][:, 0], batch["added_attention_mask"][:, 0], NI, NR)
+        ol = O.iaog_decoder_forward(Pw, cfg, dec, enc)
+        err = (ol - logits).abs().max().item()
+        o_loss = torch.nn.functional.cross_entropy(ol.permute(0, 2, 1), labels, ignore_index=-100)
+        o_loss.backward()
+        gerr = 0.0
+        for n, g in grads.items():
+            if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias"):
+                continue
+            e = (Pw[n].grad - g).abs().max().item() / (g.abs().max().item() + 1e-20)
+            if e > 1e-4:
+                print("   iaog grad mismatch", n, e, g.abs().max().item())
+            gerr = max(gerr, e)
+        print(f"iaog B={B}: oracle-vs-reference logits {err:.2e} grads(rel) {gerr:.2e} loss {float(loss):.6f}",
+              "no-grad:", nograd)
+        assert err < 1e-4 and gerr < 1e-4
+
+        # ---- reference clip + AdamW step (run_pretraining_fcmf.py:208-212,331-334) -----------
+        no_decay = ['bias', 'LayerNorm.bias', 'LayerNorm.weight']
+        params = list(model.named_parameters())
+        opt = torch.optim.AdamW([
+            {'params': [p for n, p in params if not any(nd in n for nd in no_decay)], 'weight_decay': 0.00001},
+            {'params': [p for n, p in params if any(nd in n for nd in no_decay)], 'weight_decay': 0.0}],
+            lr=3e-5, eps=1e-8)
+        total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        before = {n: p.detach().clone() for n, p in named.items()}
+        opt.step()
+        after = {n: p.detach().clone() for n, p in named.items()}
+
+        t = f"b{B}_"
+        names = sorted(grads)
+        out[t + "dec"] = dec.numpy()
+        out[t + "labels"] = labels.numpy()
+        out[t + "logits"] = logits.detach().numpy()[:, :, ::8]
+        out[t + "loss"] = np.float32(loss.item())
+        out[t + "cross_attn_nonzero"] = (cross_w[0] > 1e-30).sum(-1).numpy()
+        out[t + "total_grad_norm"] = np.float32(float(total_norm))
+        out[t + "grad_names"] = np.array(names)
+        out[t + "grad_norms"] = np.array([grads[n].norm().item() for n in names], dtype=np.float64)
+        out[t + "nograd_names"] = np.array(nograd)
+        out[t + "delta_norms"] = np.array([(after[n] - before[n]).norm().item() for n in names], dtype=np.float64)
+        srng = np.random.Generator(np.random.PCG64(7))
+        for n in IAOG_SAMPLED:
+            g = grads[n].flatten()
+            d = (after[n] - before[n]).flatten()
+            if g.numel() > 2048:
+                idx = np.sort(srng.choice(g.numel(), size=2048, replace=False))
+                if n.endswith("embedding.weight") or n.endswith("word_embeddings.weight"):
+                    # embedding tables: most rows are untouched -- sample the rows that were looked up as well
+                    H_ = grads[n].shape[1]
+                    rows = np.unique(np.concatenate([dec.numpy().ravel(), batch["input_ids"][:, 0].numpy().ravel()]))[:24]
+                    idx = np.unique(np.concatenate([idx, (rows[:, None] * H_ + np.arange(0, H_, 4)[None]).ravel()]))
+                out[t + "gidx_" + n] = idx
+                out[t + "g_" + n] = g[idx].numpy()
+                out[t + "d_" + n] = d[idx].numpy()
+            else:
+                out[t + "g_" + n] = g.numpy()
+                out[t + "d_" + n] = d.numpy()
+    np.savez_compressed(os.path.join(GOLD, "iaog_tiny.npz"), **out)
+    print("iaog fixture ok", os.path.getsize(os.path.join(GOLD, "iaog_tiny.npz")) // 1024, "KiB")
 
 
 if __name__ == "__main__":

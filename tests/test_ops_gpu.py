@@ -530,6 +530,38 @@ def test_fused_adamw_matches_torch(dev):
             assert max_err(p, r) < 2e-6
 
 
+def test_fused_adamw_resumes_from_torch_adamw_checkpoint(dev):
+    """a checkpoint written by the reference's torch.optim.AdamW (tensor `step`, its own exp_avg tensors) loads into
+    FusedAdamW AFTER it has already stepped (cached pointer tables must be dropped) and the trajectories agree"""
+    from fcmf_framework.optimization import FusedAdamW
+    shapes = [(64, 48), (48,)]
+    ps = [torch.nn.Parameter(_rand(s, dev, seed=i)) for i, s in enumerate(shapes)]
+    rs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt, ref = FusedAdamW(ps, lr=1e-3), torch.optim.AdamW(rs, lr=1e-3)
+
+    def both(it):
+        for i, (p, r) in enumerate(zip(ps, rs)):
+            g = _rand(p.shape, dev, scale=1.0, seed=100 + 10 * it + i)
+            p.grad, r.grad = g, g.cpu().clone()
+        ref.step()
+        opt.step()
+    both(0)
+    for i, r in enumerate(rs):                       # the reference runs two more steps on its own
+        r.grad = _rand(r.shape, dev, scale=1.0, seed=500 + i).cpu()
+    ref.step()
+    for p, r in zip(ps, rs):
+        p.data.copy_(r.data.to(dev))
+    sd = ref.state_dict()
+    assert torch.is_tensor(sd["state"][0]["step"])
+    opt.load_state_dict(sd)
+    assert all(isinstance(st["step"], int) for st in opt.state.values())
+    both(2)
+    for p, r in zip(ps, rs):
+        assert max_err(p, r) < 2e-6
+    for p in ps:                                     # the kernel wrote the LOADED moment tensors
+        assert max_err(opt.state[p]["exp_avg"], ref.state[rs[ps.index(p)]]["exp_avg"]) < 1e-6
+
+
 def test_bertadam_matches_golden(dev):
     import os
     from conftest import GOLD

@@ -4,6 +4,7 @@ box, where /root/reference does not exist."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLD
@@ -86,20 +87,37 @@ def test_oracle_bertadam_and_schedules():
         assert abs(opt.warmup_constant(float(x)) - wc) < 1e-12
 
 
-def test_oracle_iaog_tiny():
+@pytest.mark.parametrize("B", [3, 4])
+def test_oracle_iaog_tiny(B):
+    """IAOG logits, loss AND gradients of the oracle against the reference fixture, at two batch sizes (the decoder's
+    slot->head pairing depends on B mod n_head, mm_modeling.py:79-85)"""
     z = np.load(os.path.join(GOLD, "iaog_tiny.npz"))
+    t = f"b{B}_"
     cfg = synth.TINY_CFG
-    V, NI, NR, B, S = cfg["vocab_size"], 2, 5, 3, 16
+    V, NI, NR, S = cfg["vocab_size"], 2, 5, 16
     shapes = {k: v for k, v in synth.fcmf_param_shapes(cfg).items() if k.startswith("encoder.")}
     shapes.update(synth.iaog_decoder_param_shapes(cfg, V))
-    P = dict(synth.synth_params(shapes))
+    P = {k: v.clone().requires_grad_(True) for k, v in synth.synth_params(shapes).items()}
     P["decoder.dense.weight"] = P["encoder.bert.cell.embeddings.word_embeddings.weight"]
     batch = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, seed=5, coord_dtype=torch.float32)
-    with torch.no_grad():
-        enc = O.fcmf_encoder_forward(P, cfg, batch["input_ids"][:, 0], batch["visual_embeds_att"],
-                                     batch["roi_embeds_att"], batch["roi_coors"], batch["token_type_ids"][:, 0],
-                                     batch["attention_mask"][:, 0], batch["added_attention_mask"][:, 0], NI, NR)
-        logits = O.iaog_decoder_forward(P, cfg, torch.from_numpy(z["dec"]), enc)
-    assert (logits[:, :, ::8] - torch.from_numpy(z["logits"])).abs().max() < 1e-5
-    loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), torch.from_numpy(z["labels"]), ignore_index=-100)
-    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    enc = O.fcmf_encoder_forward(P, cfg, batch["input_ids"][:, 0], batch["visual_embeds_att"],
+                                 batch["roi_embeds_att"], batch["roi_coors"], batch["token_type_ids"][:, 0],
+                                 batch["attention_mask"][:, 0], batch["added_attention_mask"][:, 0], NI, NR)
+    logits = O.iaog_decoder_forward(P, cfg, torch.from_numpy(z[t + "dec"]), enc)
+    assert (logits.detach()[:, :, ::8] - torch.from_numpy(z[t + "logits"])).abs().max() < 1e-5
+    loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), torch.from_numpy(z[t + "labels"]), ignore_index=-100)
+    assert abs(loss.item() - float(z[t + "loss"])) < 1e-5
+    loss.backward()
+    for n, ref in zip(z[t + "grad_names"], z[t + "grad_norms"]):
+        n = str(n)
+        if n.endswith(".key.bias") or n.endswith("box_head.linears.1.bias"):
+            continue
+        assert abs(P[n].grad.norm().item() - ref) < 1e-4 * max(ref, 1e-4), n
+    for key in z.files:
+        if key.startswith(t + "g_"):
+            n = key[len(t) + 2:]
+            g = P[n].grad.flatten()
+            if (t + "gidx_" + n) in z.files:
+                g = g[torch.from_numpy(z[t + "gidx_" + n])]
+            ref = torch.from_numpy(z[key])
+            assert (g - ref).abs().max().item() < 1e-4 * max(ref.abs().max().item(), 1e-6), n
