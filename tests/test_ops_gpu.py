@@ -558,8 +558,8 @@ def test_fused_adamw_resumes_from_torch_adamw_checkpoint(dev):
     both(2)
     for p, r in zip(ps, rs):
         assert max_err(p, r) < 2e-6
-    for p in ps:                                     # the kernel wrote the LOADED moment tensors
-        assert max_err(opt.state[p]["exp_avg"], ref.state[rs[ps.index(p)]]["exp_avg"]) < 1e-6
+    for p, r in zip(ps, rs):                         # the kernel wrote the LOADED moment tensors
+        assert max_err(opt.state[p]["exp_avg"], ref.state[r]["exp_avg"]) < 1e-6
 
 
 def test_bertadam_matches_golden(dev):
