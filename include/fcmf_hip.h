@@ -247,6 +247,44 @@ int fcmf_bertadam(float* p, const float* g, float* m, float* v, int64_t n, float
                   float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                   double* scratch, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * ResNet-152 trunk (fcmf_framework/resnet_utils.py:13-30,39-56 driving torchvision's resnet152:
+ * conv1/bn1/relu/maxpool/layer1..4, then adaptive_avg_pool2d / global mean).  Activations are NHWC
+ * ([N*H*W, C] row-major) so every convolution is an fcmf_gemm: 1x1 stride-1 convolutions directly on the
+ * activation matrix, all others on the patch matrix written by fcmf_conv_im2col; weights are passed as
+ * [Cout, kh*kw*Cin] with k = (r, s, c).
+ *
+ * fcmf_conv_im2col: dst[row, (r*kw + s)*C + c] = src(n, ho*stride + r - pad, wo*stride + s - pad, c) or 0,
+ * row = (n*Ho + ho)*Wo + wo, Ho = (H + 2*pad - kh)/stride + 1; columns kh*kw*C .. Kpad-1 are zero (the stem's
+ * K = 147 is padded to a multiple of 32).  src element (n,h,w,c) at n*sn + h*sh + w*sw + c*sc: NCHW float32
+ * crops and NHWC activations alike.  (nn.Conv2d's input gather, torchvision Bottleneck conv2 / downsample.0 / conv1) */
+int fcmf_conv_im2col(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int H, int W, int C,
+                     int64_t sn, int64_t sh, int64_t sw, int64_t sc, int kh, int kw, int stride, int pad,
+                     int Kpad, void* stream);
+/* GROUPED BatchNorm2d batch statistics.  The reference calls the trunk once per image index / per (image, ROI)
+ * with B crops each (run_multimodal_fcmf.py:449-457) in train() mode (:431): rows are packed group-major, group g
+ * = rows [g*rows_per_group, (g+1)*rows_per_group), and every group gets ITS OWN statistics.
+ * sums: double [groups, C, 2] (sum, sum of squares), overwritten. */
+int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group, int groups, int C, int dtype, void* stream);
+/* sums != NULL (training): scale/shift [groups, C] from each group's batch mean and biased variance
+ * (y = x*scale + shift == (x-mean)/sqrt(var+eps)*gamma + beta); running_mean / running_var receive one
+ * momentum update per group in group order with the unbiased variance (nn.BatchNorm2d over `groups` calls).
+ * sums == NULL (eval): scale/shift [C] from the running statistics.  count = elements per (group, channel). */
+int fcmf_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float* scale, float* shift, int C, int groups, int64_t count,
+                     float momentum, float eps, void* stream);
+/* y = relu?(x * scale[g] + shift[g] (+ res)), g = row / rows_per_group (eval: rows_per_group = rows); y may alias x.
+ * (bn -> relu, and the bottleneck's bn3 -> += identity -> relu) */
+int fcmf_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows,
+                  int C, int64_t rows_per_group, int relu, int dtype, void* stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC: [N,H,W,C] -> [N,(H-1)/2+1,(W-1)/2+1,C] */
+int fcmf_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+/* F.adaptive_avg_pool2d(x, [oh, ow]) of an NHWC activation, float32 output: layout 0 = [N, C, oh, ow] (what
+ * myResNetImg returns, resnet_utils.py:24), layout 1 = [N, oh*ow, C] (the [B, 49, 2048] token layout the driver
+ * builds with view/permute, run_multimodal_fcmf.py:451).  oh = ow = 1 is myResNetRoI's x.mean(3).mean(2) (:48). */
+int fcmf_adaptive_avgpool(const void* x, float* y, int N, int H, int W, int C, int oh, int ow, int layout,
+                          int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,318 @@
+// ResNet-152 trunk helpers for gfx950 (reference: fcmf_framework/resnet_utils.py:13-56 driving torchvision's
+// resnet152).  Activations are NHWC ([N*H*W, C] row-major), so every convolution is a GEMM of the step's MFMA kernels
+// (gemm.hip): 1x1 / stride 1 directly on the activation matrix, everything else on the patch matrix built here.
+//   im2col_kernel        patch matrix [N*Ho*Wo, Kpad] (k = (r, s, c), zero padding and zero tail columns)
+//   bn_stats_kernel      GROUPED BatchNorm batch statistics: per (call group, channel) sum / sum of squares (double)
+//   bn_finalize_kernel   statistics -> per-(group, channel) scale/shift + the running-statistics EMA in call order
+//   bn_apply_kernel      y = relu?(x * scale + shift (+ residual)), in place
+//   maxpool3x3s2_kernel  3x3 / stride 2 / pad 1
+//   avgpool_kernel       adaptive average pool to [N, C, oh, ow] (the reference's output layout) or [N, oh*ow, C]
+// All of them are HBM-bound streaming kernels: 8/16-byte accesses, a wave reads whole rows.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// patch matrix.  src element (n, h, w, c) at n*sn + h*sh + w*sw + c*sc (any layout: NCHW float32 crops, NHWC
+// activations); dst[row, (r*kw + s)*C + c], row = (n*Ho + ho)*Wo + wo; columns >= kh*kw*C are zero.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void im2col_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int N, int H, int W,
+                                                     int C, int64_t sn, int64_t sh, int64_t sw, int64_t sc, int kh, int kw,
+                                                     int stride, int pad, int Ho, int Wo, int Kpad) {
+  const int64_t rows = (int64_t)N * Ho * Wo;
+  const int K = kh * kw * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < rows * Kpad; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / Kpad;
+    const int col = (int)(idx - row * Kpad);
+    float v = 0.f;
+    if (col < K) {
+      const int c = col % C, tap = col / C, s = tap % kw, r = tap / kw;
+      const int wo = (int)(row % Wo), ho = (int)((row / Wo) % Ho);
+      const int64_t n = row / ((int64_t)Wo * Ho);
+      const int hi = ho * stride + r - pad, wi = wo * stride + s - pad;
+      if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = to_f32<TS>(src[n * sn + hi * sh + wi * sw + c * sc]);
+    }
+    dst[idx] = from_f32<TD>(v);
+  }
+}
+
+// NHWC source with C % 8 == 0 (every convolution but the stem), same dtype both sides: one 16-byte (bf16) or two
+// 16-byte (f32) accesses per 8 channels; a wave writes 64 consecutive 8-channel pieces of the patch matrix.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_nhwc8_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H,
+                                                           int W, int C, int kh, int kw, int stride, int pad, int Ho, int Wo,
+                                                           int Kpad) {
+  const int64_t rows = (int64_t)N * Ho * Wo;
+  const int K8 = Kpad >> 3, C8 = C >> 3, Kv = kh * kw * C8;
+  typedef T vec8 __attribute__((ext_vector_type(8)));
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < rows * K8; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / K8;
+    const int cv = (int)(idx - row * K8);
+    vec8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(0.f);
+    if (cv < Kv) {
+      const int c8 = cv % C8, tap = cv / C8, s = tap % kw, r = tap / kw;
+      const int wo = (int)(row % Wo), ho = (int)((row / Wo) % Ho);
+      const int64_t n = row / ((int64_t)Wo * Ho);
+      const int hi = ho * stride + r - pad, wi = wo * stride + s - pad;
+      if (hi >= 0 && hi < H && wi >= 0 && wi < W)
+        v = *reinterpret_cast<const vec8*>(src + ((n * H + hi) * W + wi) * C + c8 * 8);
+    }
+    *reinterpret_cast<vec8*>(dst + idx * 8) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// grouped batch statistics.  grid (channel slabs of 256, row chunks, groups); a thread owns 4 adjacent channels and
+// every (256 / vecs-per-row)-th row of its chunk; waves are reduced through LDS; one double atomic per channel and
+// workgroup.  sums [G, C, 2] (sum, sum of squares) must be zero on entry.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, int C,
+                                                       int64_t rows_per_group, int chunk) {
+  __shared__ float4 red[2][256];
+  const int slab_c = C < 256 ? C : 256, vpr = slab_c >> 2, rpp = 256 / vpr;      // vectors per row, rows per pass
+  const int cv = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
+  const int c0 = blockIdx.x * 256 + cv * 4;
+  const int g = blockIdx.z;
+  const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = min(rows_per_group, r0 + chunk);
+  float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+  if (c0 < C) {
+    const T* base = x + ((int64_t)g * rows_per_group) * C + c0;
+    for (int64_t r = r0 + rsub; r < r1; r += rpp) {
+      const float4 v = Vec4<T>::load(base + r * C);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (rsub == 0 && c0 < C) {
+    double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+    for (int k = 0; k < rpp; ++k) {
+      const float4 a = red[0][k * vpr + cv], b = red[1][k * vpr + cv];
+      ds[0] += a.x; ds[1] += a.y; ds[2] += a.z; ds[3] += a.w;
+      dq[0] += b.x; dq[1] += b.y; dq[2] += b.z; dq[3] += b.w;
+    }
+    double* o = sums + ((int64_t)g * C + c0) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { atomicAdd(o + 2 * e, ds[e]); atomicAdd(o + 2 * e + 1, dq[e]); }
+  }
+}
+
+// one thread per channel.  training: group g's batch mean / biased variance -> scale/shift[g]; running statistics
+// take one EMA update per group IN GROUP ORDER with the unbiased variance (nn.BatchNorm2d, one reference call per
+// group).  eval (sums == NULL): scale/shift[0] from the running statistics.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, float* __restrict__ scale,
+                                                          float* __restrict__ shift, int C, int G, double count,
+                                                          float momentum, float eps) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float w = gamma[c], b = beta[c];
+  if (!sums) {
+    const float sc = w / sqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = b - rmean[c] * sc;
+    return;
+  }
+  float rm = rmean[c], rv = rvar[c];
+  for (int g = 0; g < G; ++g) {
+    const double s = sums[((int64_t)g * C + c) * 2], q = sums[((int64_t)g * C + c) * 2 + 1];
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    var = var > 0 ? var : 0;
+    const float sc = w / sqrtf((float)var + eps);
+    scale[(int64_t)g * C + c] = sc;
+    shift[(int64_t)g * C + c] = b - (float)mean * sc;
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    rm = (1.f - momentum) * rm + momentum * (float)mean;
+    rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+  }
+  rmean[c] = rm;
+  rvar[c] = rv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int64_t rows, int C, int64_t rows_per_group, int relu) {
+  const int C4 = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < rows * C4; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / C4;
+    const int c = (int)(idx - row * C4) * 4;
+    const int64_t g = row / rows_per_group;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + g * C + c);
+    float4 v = Vec4<T>::load(x + row * C + c);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (res) {
+      const float4 r = Vec4<T>::load(res + row * C + c);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    Vec4<T>::store(y + row * C + c, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                           int C, int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C4) * 4;
+    const int64_t p = idx / C4;
+    const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho);
+    const int64_t n = p / ((int64_t)Wo * Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = ho * 2 + r - 1;
+      if (hi < 0 || hi >= H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wi = wo * 2 + s - 1;
+        if (wi < 0 || wi >= W) continue;
+        const float4 v = Vec4<T>::load(x + ((n * H + hi) * W + wi) * C + c);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    Vec4<T>::store(y + p * C + c, m);
+  }
+}
+
+// adaptive average pool (F.adaptive_avg_pool2d: window [floor(i*H/oh), ceil((i+1)*H/oh)) ); float32 output in
+// NCHW ([N, C, oh, ow], layout = 0: what myResNetImg returns) or token-major ([N, oh*ow, C], layout = 1)
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                                                      int oh, int ow, int layout) {
+  const int64_t total = (int64_t)N * oh * ow * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const int64_t p = idx / C;
+    const int j = (int)(p % ow), i = (int)((p / ow) % oh);
+    const int64_t n = p / ((int64_t)ow * oh);
+    const int h0 = (i * H) / oh, h1 = ((i + 1) * H + oh - 1) / oh;
+    const int w0 = (j * W) / ow, w1 = ((j + 1) * W + ow - 1) / ow;
+    float s = 0.f;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) s += to_f32<T>(x[((n * H + h) * W + w) * C + c]);
+    s /= (float)((h1 - h0) * (w1 - w0));
+    if (layout == 0) y[((n * C + c) * oh + i) * ow + j] = s;
+    else y[idx] = s;
+  }
+}
+
+static inline int grid_for(int64_t work) {
+  const int64_t b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+extern "C" int fcmf_conv_im2col(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int H, int W, int C,
+                                int64_t sn, int64_t sh, int64_t sw, int64_t sc, int kh, int kw, int stride, int pad,
+                                int Kpad, void* stream) {
+  if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || C <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 ||
+      Kpad < kh * kw * C)
+    return FCMF_ERR_ARG;
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t rows = (int64_t)N * Ho * Wo;
+  const bool nhwc = sc == 1 && sw == C && sh == (int64_t)W * C && sn == (int64_t)H * W * C;
+  const bool al16 = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  if (nhwc && C % 8 == 0 && Kpad % 8 == 0 && src_dtype == dst_dtype && al16) {
+    const int g = grid_for(rows * (Kpad / 8));
+    if (src_dtype == FCMF_BF16)
+      hipLaunchKernelGGL((im2col_nhwc8_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, H, W, C, kh, kw, stride, pad, Ho, Wo, Kpad);
+    else if (src_dtype == FCMF_F32)
+      hipLaunchKernelGGL((im2col_nhwc8_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, N, H, W, C, kh, kw, stride, pad, Ho, Wo, Kpad);
+    else return FCMF_ERR_UNSUPPORTED;
+    FCMF_CHECK_LAUNCH();
+    return FCMF_OK;
+  }
+  const int g = grid_for(rows * Kpad);
+#define FCMF_IM2COL(TS, TD) \
+  hipLaunchKernelGGL((im2col_kernel<TS, TD>), dim3(g), dim3(256), 0, st, (const TS*)src, (TD*)dst, N, H, W, C, sn, sh, sw, sc, kh, kw, stride, pad, Ho, Wo, Kpad)
+  if (src_dtype == FCMF_F32 && dst_dtype == FCMF_F32) FCMF_IM2COL(float, float);
+  else if (src_dtype == FCMF_F32 && dst_dtype == FCMF_BF16) FCMF_IM2COL(float, bf16_t);
+  else if (src_dtype == FCMF_BF16 && dst_dtype == FCMF_BF16) FCMF_IM2COL(bf16_t, bf16_t);
+  else if (src_dtype == FCMF_BF16 && dst_dtype == FCMF_F32) FCMF_IM2COL(bf16_t, float);
+  else return FCMF_ERR_UNSUPPORTED;
+#undef FCMF_IM2COL
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group, int groups, int C, int dtype,
+                             void* stream) {
+  if (!x || !sums || rows_per_group <= 0 || groups <= 0 || C <= 0 || C % 4 != 0 || (C < 256 && 256 % (C / 4) != 0) ||
+      (C > 256 && C % 256 != 0))
+    return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)groups * C, st) != hipSuccess) return FCMF_ERR_LAUNCH;
+  // chunk: enough workgroups to fill the chip, at most 1024 rows per workgroup (short float partial sums)
+  const int slabs = (C + 255) / 256;
+  int64_t chunks = (2048 + (int64_t)slabs * groups - 1) / ((int64_t)slabs * groups);
+  int64_t chunk = (rows_per_group + chunks - 1) / chunks;
+  if (chunk > 1024) chunk = 1024;
+  if (chunk < 16) chunk = 16;
+  chunks = (rows_per_group + chunk - 1) / chunk;
+  if (chunks > 65535 || groups > 65535) return FCMF_ERR_UNSUPPORTED;
+  dim3 grid(slabs, (unsigned)chunks, groups);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((bn_stats_kernel<float>), grid, dim3(256), 0, st, (const float*)x, sums, C, rows_per_group, (int)chunk);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, sums, C, rows_per_group, (int)chunk);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float* scale, float* shift, int C, int groups, int64_t count,
+                                float momentum, float eps, void* stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0 || groups <= 0) return FCMF_ERR_ARG;
+  if (sums && count <= 0) return FCMF_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
+                     gamma, beta, running_mean, running_var, scale, shift, C, groups, (double)count, momentum, eps);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,
+                             int64_t rows, int C, int64_t rows_per_group, int relu, int dtype, void* stream) {
+  if (!x || !y || !scale || !shift || rows < 0 || C <= 0 || C % 4 != 0 || rows_per_group <= 0) return FCMF_ERR_ARG;
+  if (rows == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for(rows * (C / 4));
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)res, (float*)y, scale, shift, rows, C, rows_per_group, relu);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, scale, shift, rows, C, rows_per_group, relu);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return FCMF_ERR_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for((int64_t)N * Ho * Wo * (C / 4));
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((maxpool3x3s2_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, Ho, Wo);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((maxpool3x3s2_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_adaptive_avgpool(const void* x, float* y, int N, int H, int W, int C, int oh, int ow, int layout,
+                                     int dtype, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || oh <= 0 || ow <= 0 || (layout != 0 && layout != 1)) return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for((int64_t)N * oh * ow * C);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((avgpool_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, y, N, H, W, C, oh, ow, layout);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((avgpool_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, y, N, H, W, C, oh, ow, layout);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}

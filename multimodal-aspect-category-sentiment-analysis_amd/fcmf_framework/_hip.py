@@ -66,6 +66,12 @@ SIGNATURES = {
     "fcmf_multi_adamw": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _i, _f, _f,
                          _f, _i, _vp, _f, _vp],
     "fcmf_bertadam": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp],
+    "fcmf_conv_im2col": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _vp],
+    "fcmf_bn_stats": [_vp, _vp, _i64, _i, _i, _i, _vp],
+    "fcmf_bn_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _f, _f, _vp],
+    "fcmf_bn_apply": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _vp],
+    "fcmf_maxpool3x3s2": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "fcmf_adaptive_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 
 _lib = None

@@ -157,3 +157,77 @@ def synth_batch(B, cfg, S=128, num_imgs=7, num_roi=36, num_aspects=6, num_labels
         attention_mask=torch.from_numpy(att), added_attention_mask=torch.from_numpy(added),
         visual_embeds_att=torch.from_numpy(vis), roi_embeds_att=torch.from_numpy(roi.astype(np.float32)),
         roi_coors=torch.from_numpy(coors).to(coord_dtype), labels=torch.from_numpy(labels))
+
+
+# ---------------------------------------------------------------------------------------
+# ResNet-152 trunk (torchvision layout: v1.5 bottleneck, stride on the 3x3; resnet_utils.py:13-24 consumes
+# conv1/bn1/relu/maxpool/layer1..4).  torchvision is absent offline: shapes follow its published state-dict.
+# ---------------------------------------------------------------------------------------
+RESNET152_LAYERS = (3, 8, 36, 3)
+RESNET_TINY_LAYERS = (1, 2, 2, 1)      # same block type, fewer blocks: test-size trunk
+
+
+def resnet_param_shapes(layers=RESNET152_LAYERS, base=64, with_fc=False):
+    """state-dict keys -> shapes of a torchvision Bottleneck ResNet (parameters AND BatchNorm buffers)"""
+    out = OrderedDict()
+
+    def bn(prefix, c):
+        out[f"{prefix}.weight"] = (c,)
+        out[f"{prefix}.bias"] = (c,)
+        out[f"{prefix}.running_mean"] = (c,)
+        out[f"{prefix}.running_var"] = (c,)
+        out[f"{prefix}.num_batches_tracked"] = ()
+    out["conv1.weight"] = (base, 3, 7, 7)
+    bn("bn1", base)
+    inplanes = base
+    for li, nblk in enumerate(layers):
+        planes = base * (2 ** li)
+        for b in range(nblk):
+            p = f"layer{li + 1}.{b}"
+            out[f"{p}.conv1.weight"] = (planes, inplanes, 1, 1)
+            bn(f"{p}.bn1", planes)
+            out[f"{p}.conv2.weight"] = (planes, planes, 3, 3)
+            bn(f"{p}.bn2", planes)
+            out[f"{p}.conv3.weight"] = (planes * 4, planes, 1, 1)
+            bn(f"{p}.bn3", planes * 4)
+            if b == 0:
+                out[f"{p}.downsample.0.weight"] = (planes * 4, inplanes, 1, 1)
+                bn(f"{p}.downsample.1", planes * 4)
+            inplanes = planes * 4
+    if with_fc:
+        out["fc.weight"] = (1000, inplanes)
+        out["fc.bias"] = (1000,)
+    return out
+
+
+def synth_resnet_params(shapes, seed=0):
+    """Kaiming-normal (fan_out) conv weights as torchvision initialises them; BatchNorm weight 1 + N(0, 0.02)
+    (0.25 x that on the last BN of a block so that 50 residual additions stay tame in eval mode), bias N(0, 0.02),
+    running_mean N(0, 0.1), running_var U(0.5, 1.5), num_batches_tracked 0."""
+    out = OrderedDict()
+    for name, shape in shapes.items():
+        rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1 & 0xFFFFFFFF)))
+        if name.endswith("num_batches_tracked"):
+            out[name] = torch.zeros((), dtype=torch.long)
+            continue
+        if len(shape) == 4:
+            fan_out = shape[0] * shape[2] * shape[3]
+            a = rng.standard_normal(size=shape, dtype=np.float32) * np.float32(np.sqrt(2.0 / fan_out))
+        elif name.endswith("running_var"):
+            a = (0.5 + rng.random(size=shape, dtype=np.float32)).astype(np.float32)
+        elif name.endswith("running_mean"):
+            a = 0.1 * rng.standard_normal(size=shape, dtype=np.float32)
+        elif name.endswith(".weight") and len(shape) == 1:
+            a = 1.0 + 0.02 * rng.standard_normal(size=shape, dtype=np.float32)
+            if name.endswith("bn3.weight"):
+                a = 0.25 * a
+        else:
+            a = 0.02 * rng.standard_normal(size=shape, dtype=np.float32)
+        out[name] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return out
+
+
+def synth_crops(n, size=224, seed=0):
+    """[n, 3, size, size] float32 'normalised image' crops (what image_process.py hands the trunk)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(rng.standard_normal((n, 3, size, size), dtype=np.float32))

@@ -1,0 +1,192 @@
+"""ResNet-152 trunk (reference resnet_utils.py:13-56 + torchvision resnet152) on the HIP kernels, through the C ABI.
+
+Oracle = oracle/resnet_oracle.py, a torch-CPU restatement on F.conv2d / F.batch_norm / F.max_pool2d.  PARITY UNPINNED
+vs torchvision (not installed, no reference fixture exists): what is checked is the build against that restatement.
+Tolerances: fp32 mode 1e-3 relative to the output scale (north-star bound), bf16 mode 5e-2.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import max_err
+from oracle import resnet_oracle as RO
+import synthetic_data as synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _set(dtype):
+    from fcmf_framework import ops
+    ops.set_compute_dtype(dtype)
+    ops.shadows.clear()
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _build(layers, dev, seed=0):
+    from fcmf_framework.resnet import ResNet
+    shapes = synth.resnet_param_shapes(layers)
+    P = synth.synth_resnet_params(shapes, seed)
+    m = ResNet(layers)
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not unexpected and all(k.startswith("fc.") for k in missing), (missing, unexpected)
+    return m.to(dev), P
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw", [(3, 64, 7, 2, 3, 37), (64, 64, 3, 1, 1, 14), (128, 128, 3, 2, 1, 15),
+                                                      (64, 256, 1, 1, 0, 9), (256, 512, 1, 2, 0, 14)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_matches_torch(dev, cin, cout, k, stride, pad, hw, dtype):
+    from fcmf_framework import resnet as R
+    _set(dtype)
+    try:
+        conv = R.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False)
+        conv.weight.data = _rand(conv.weight.shape, 1, (2.0 / (cin * k * k)) ** 0.5)
+        x = _rand((3, cin, hw, hw + 2), 2)
+        ref = F.conv2d(x, conv.weight.data, stride=stride, padding=pad)
+        y = conv.to(dev)(x.to(dev))                        # NCHW in, NCHW-shaped out (module API)
+        assert y.shape == ref.shape
+        tol = 1e-4 if dtype == torch.float32 else 3e-2
+        assert max_err(y, ref) < tol * ref.abs().max().item()
+        # channels_last input takes the in-place (no gather) path for 1x1 / stride 1
+        y2 = conv(x.to(dev).contiguous(memory_format=torch.channels_last))
+        assert max_err(y2, ref) < tol * ref.abs().max().item()
+    finally:
+        _set(torch.float32)
+
+
+@pytest.mark.parametrize("C,groups", [(64, 1), (128, 3), (256, 2), (1024, 2)])
+def test_grouped_batchnorm_train_and_eval(dev, C, groups):
+    """training: per-group batch statistics + `groups` sequential running-statistics updates == `groups` separate
+    nn.BatchNorm2d calls; eval: the running statistics"""
+    from fcmf_framework import resnet as R
+    _set(torch.float32)
+    B, hw = 2, 5
+    x = _rand((groups * B, C, hw, hw), 3) * 1.7 + 0.3
+    bn = R.BatchNorm2d(C)
+    bn.weight.data, bn.bias.data = 1 + 0.1 * _rand((C,), 4), 0.1 * _rand((C,), 5)
+    bn.running_mean.data, bn.running_var.data = 0.1 * _rand((C,), 6), 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(7))
+    ref = copy.deepcopy(bn)
+    ref.__class__ = torch.nn.BatchNorm2d
+    bn = bn.to(dev)
+    bn.groups = groups
+    outs = [torch.nn.BatchNorm2d.forward(ref, xg) for xg in x.chunk(groups, 0)]
+    y = bn(x.to(dev))
+    assert max_err(y, torch.cat(outs, 0)) < 2e-5
+    assert max_err(bn.running_mean, ref.running_mean) < 1e-6
+    assert max_err(bn.running_var, ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == groups
+    bn.eval(); ref.eval()
+    assert max_err(bn(x.to(dev)), torch.nn.BatchNorm2d.forward(ref, x)) < 2e-5
+
+
+def test_pools_match_torch(dev):
+    from fcmf_framework import resnet as R
+    _set(torch.float32)
+    x = _rand((2, 64, 13, 16), 8)
+    assert max_err(R.MaxPool2d()(x.to(dev)), F.max_pool2d(x, 3, 2, 1)) == 0.0
+    for size in ((7, 7), (1, 1), (3, 5)):
+        assert max_err(R.AdaptiveAvgPool2d(size)(x.to(dev)), F.adaptive_avg_pool2d(x, size)) < 1e-6
+    tok = R.adaptive_avgpool_nhwc(R._nhwc(x.to(dev)), 7, 7, tokens=True)
+    assert max_err(tok, F.adaptive_avg_pool2d(x, (7, 7)).view(2, 64, 49).permute(0, 2, 1)) < 1e-6
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_small_trunk_matches_oracle_fp32(dev, training):
+    """a (1,2,2,1)-block trunk of the same Bottleneck type on 64x64 crops, 3 call groups of 2 crops:
+    myResNetImg / myResNetRoI outputs and (training) the BatchNorm buffers against the oracle"""
+    from fcmf_framework.resnet_utils import myResNetImg, myResNetRoI
+    _set(torch.float32)
+    layers, groups, B = synth.RESNET_TINY_LAYERS, 3, 2
+    m, P = _build(layers, dev)
+    x = synth.synth_crops(groups * B, 64, seed=1)
+    Po = {k: v.clone() for k, v in P.items()}
+    o_img = RO.my_resnet_img(Po, x, layers, 2, training=training, groups=groups)
+    Po2 = {k: v.clone() for k, v in P.items()}
+    o_roi = RO.my_resnet_roi(Po2, x, layers, training=training, groups=groups)
+    img, roi = myResNetImg(m, False, dev), myResNetRoI(copy.deepcopy(m), False, dev)
+    img.train(training); roi.train(training)
+    y_img = img.forward_groups(x.to(dev), groups, att_size=2)
+    y_roi = roi.forward_groups(x.to(dev), groups)
+    assert y_img.shape == o_img.shape and y_roi.shape == o_roi.shape
+    assert not y_img.requires_grad
+    assert max_err(y_img, o_img) < 1e-3 * o_img.abs().max().item()
+    assert max_err(y_roi, o_roi) < 1e-3 * o_roi.abs().max().item()
+    sd = img.resnet.state_dict()
+    for k in ("bn1", "layer2.1.bn2", "layer4.0.downsample.1", "layer3.0.bn3"):
+        tol = 1e-4 if training else 0.0
+        assert max_err(sd[k + ".running_mean"], Po[k + ".running_mean"]) <= tol * (1 + Po[k + ".running_mean"].abs().max().item())
+        assert max_err(sd[k + ".running_var"], Po[k + ".running_var"]) <= tol * (1 + Po[k + ".running_var"].abs().max().item())
+        assert int(sd[k + ".num_batches_tracked"]) == int(Po[k + ".num_batches_tracked"])
+    if training:
+        # one forward() call per group (the reference's loop) == the batched pass
+        m2, _ = _build(layers, dev)
+        img2 = myResNetImg(m2, False, dev).train()
+        ys = torch.cat([img2(xg.to(dev), att_size=2) for xg in x.chunk(groups, 0)], 0)
+        assert max_err(ys, y_img) < 1e-5 * o_img.abs().max().item()
+
+
+def test_resnet152_full_depth_eval_and_bf16(dev):
+    """the real [3, 8, 36, 3] trunk on 224x224 crops: fp32 within 1e-3 of the oracle, bf16 (MFMA path) within 5e-2;
+    output layouts of the reference ([B,2048,7,7] -> view(-1,2048,49).permute(0,2,1)) and of the batched driver"""
+    from fcmf_framework.resnet import resnet152
+    from fcmf_framework.resnet_utils import myResNetImg
+    layers = synth.RESNET152_LAYERS
+    P = synth.synth_resnet_params(synth.resnet_param_shapes(layers))
+    x = synth.synth_crops(2, 224, seed=3)
+    ref = RO.my_resnet_img({k: v.clone() for k, v in P.items()}, x, layers, 7)
+    m = resnet152()
+    m.load_state_dict(P, strict=False)
+    img = myResNetImg(m.to(dev), False, dev).eval()
+    scale = ref.abs().max().item()
+    try:
+        _set(torch.float32)
+        y = img(x.to(dev))
+        assert y.shape == (2, 2048, 7, 7)
+        assert max_err(y, ref) < 1e-3 * scale, max_err(y, ref) / scale
+        tok = img.forward_groups(x.to(dev), 1, 7, tokens=True)
+        assert torch.equal(tok, y.view(-1, 2048, 49).permute(0, 2, 1))
+        _set(torch.bfloat16)
+        yb = img(x.to(dev))
+        rel = (yb.cpu() - ref).norm().item() / ref.norm().item()
+        assert rel < 5e-2, rel
+    finally:
+        _set(torch.float32)
+
+
+def test_extract_features_matches_reference_loop_order(dev):
+    """run_multimodal_fcmf.py:449-460: per-image and per-(image, ROI) calls in train() mode == two batched passes"""
+    from fcmf_framework.resnet_utils import extract_features, myResNetImg, myResNetRoI
+    _set(torch.float32)
+    layers, B, NI, NR = synth.RESNET_TINY_LAYERS, 2, 2, 3
+    m, P = _build(layers, dev)
+    t_img = synth.synth_crops(B * NI, 224, seed=5).view(B, NI, 3, 224, 224)[..., :64, :64].contiguous()
+    roi_img = synth.synth_crops(B * NI * NR, 64, seed=6).view(B, NI, NR, 3, 64, 64)
+    Pi, Pr = {k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in P.items()}
+    # the reference's loops, on the oracle (one call per group, BatchNorm buffers carried from call to call)
+    vis = torch.stack([RO.my_resnet_img(Pi, t_img[:, i], layers, 7, training=True).view(-1, 2048, 49).permute(0, 2, 1)
+                       for i in range(NI)], 1)
+    roi = torch.stack([torch.stack([RO.my_resnet_roi(Pr, roi_img[:, i, r], layers, training=True) for r in range(NR)], 1)
+                       for i in range(NI)], 1)
+    ri, rr = myResNetImg(m, False, dev).train(), myResNetRoI(copy.deepcopy(m), False, dev).train()
+    v, r = extract_features(ri, rr, t_img.to(dev), roi_img.to(dev).double())      # ROI crops arrive as float64
+    assert v.shape == (B, NI, 49, 2048) and r.shape == (B, NI, NR, 2048)
+    assert max_err(v, vis) < 1e-3 * vis.abs().max().item()
+    assert max_err(r, roi) < 1e-3 * roi.abs().max().item()
+    assert max_err(rr.resnet.bn1.running_var, Pr["bn1.running_var"]) < 1e-4
+
+
+def test_fine_tune_cnn_is_loud(dev):
+    from fcmf_framework._hip import HipLibraryError
+    from fcmf_framework.resnet_utils import myResNetImg
+    m, _ = _build(synth.RESNET_TINY_LAYERS, dev)
+    with pytest.raises(HipLibraryError):
+        myResNetImg(m, True, dev)(synth.synth_crops(1, 64).to(dev))
+    with pytest.raises(HipLibraryError):
+        myResNetImg(m, False, dev)(synth.synth_crops(1, 64))          # CPU tensor: no fallback
