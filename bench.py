@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
-"""FCMF fine-tune throughput on MI355X: train samples/sec (fwd + bwd + clip + AdamW step).
+"""FCMF training throughput on MI355X: train samples/sec (fwd + bwd + clip + AdamW step).
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1] per GPU: FCMF-base (PhoBERT-base geometry: H768 L12 heads12
-I3072 vocab 64001) bf16, batch 64 reviews x 6 aspects, seq 128, 7 images x (49 patches + 36 ROIs),
-precomputed ResNet-152 features, dropout on (p=0.1), 4-group AdamW + clip 1.0 + linear schedule.
-1 sample = 1 review = 6 aspect forwards (what the reference's tqdm counts).  Weak scaling: every
-rank processes its own 64-review shard; one gradient all-reduce (RCCL) per step.
-Synthetic data, random-init weights (no dataset / checkpoint is reachable offline); inputs are
-resident in HBM before the timed region.
+Default workload (`--workload fcmf`, the headline metric) = BASELINE.json configs[1] per GPU: FCMF-base (PhoBERT-base
+geometry: H768 L12 heads12 I3072 vocab 64001) bf16, batch 64 reviews x 6 aspects, seq 128, 7 images x (49 patches +
+36 ROIs), precomputed ResNet-152 features, dropout on (p=0.1), 4-group AdamW + clip 1.0 + linear schedule.
+1 sample = 1 review = 6 aspect forwards (what the reference's tqdm counts).  Weak scaling: every rank processes its
+own 64-review shard; one gradient all-reduce (RCCL) per step.  Synthetic data, random-init weights (no dataset /
+checkpoint is reachable offline); inputs are resident in HBM before the timed region.
 
-One JSON line on stdout (rank 0).  `roofline` describes the dominant kernel (the bf16 MFMA GEMM):
-achieved = executed GEMM FLOPs / summed launch durations measured with HIP events on the launch
-stream during the last timed step.  `cpu_baseline` times the CPU oracle (a port, not the product)
-on config C0 (B=4) on this host's cores.
+Other workloads print their OWN line (never mixed into the headline metric):
+  --workload iaog    IAOG seq2seq pre-training step (BASELINE configs[3] geometry per GPU: B=64, seq 128, Ld=12,
+                     vocab 64001, 4 ROIs as run_pretraining_fcmf.py defaults), fused vocabulary projection + loss
+  --workload resnet  the ResNet-152 feature extractor of the step: crops/s of the batched trunk
+
+One JSON line on stdout (rank 0).  `roofline` describes the dominant kernel (the bf16 MFMA GEMM family):
+achieved = executed GEMM FLOPs / summed launch durations measured with HIP events on the launch stream during the
+last timed step.  `cpu_baseline` times the CPU oracle (a port, not the product) on config C0 (B=4) on this host.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -35,6 +40,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table); ~6.3 TB/s is what a streaming copy achieves
 
 BASE_CFG = dict(vocab_size=64001, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                 intermediate_size=3072, max_position_embeddings=258, type_vocab_size=1, pad_token_id=1,
@@ -54,7 +60,7 @@ def param_groups(model, lr_enc=7e-5, lr_head=7e-4):
     return g
 
 
-def algorithmic_flops_per_sample(cfg, S, NI, P, N, A, pruned):
+def algorithmic_flops_per_sample(cfg, S, NI, P, N, A):
     """SURVEY.md section 8(d) formula (forward, per aspect) -> fwd+bwd (x3) per sample (x A)."""
     H, I, Lyr = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
 
@@ -66,33 +72,295 @@ def algorithmic_flops_per_sample(cfg, S, NI, P, N, A, pruned):
     return 3 * A * dense
 
 
-def cpu_baseline(threads_note):
-    """the CPU oracle (torch-CPU restatement, `port`) on config C0: B=4, fp32, dropout on, AdamW"""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
+    """the CPU oracle (torch-CPU restatement, `port`) on config C0: B=4, fp32, dropout on, clip + AdamW:
+    1 warm-up step + 3 timed steps"""
     import synthetic_data as synth
     from oracle import fcmf_oracle as O
     # 16 threads = the CPU share of a one-GPU box on this pool and the fastest setting measured on it
     # (tests/oracle_thread_scan.py: 16 -> 0.53, 32 -> 0.35, 64 -> 0.16, 128 -> 0.04 samples/s fwd+bwd)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    cfg, NI, NR, B = synth.BASE_CFG, 7, 36, 4
+    cfg, NI, NR, B, TIMED = synth.BASE_CFG, 7, 36, 4, 3
     P = {k: v.requires_grad_(True) for k, v in synth.synth_params(synth.fcmf_param_shapes(cfg)).items()}
     groups = O.fcmf_param_groups(list(P))
     opt = torch.optim.AdamW([dict(params=[P[n] for n in g["names"]], weight_decay=g["weight_decay"], lr=g["lr"])
                              for g in groups], lr=7e-4)
 
-    def step(bsz, seed):
-        batch = synth.synth_batch(bsz, cfg, S=128, num_imgs=NI, num_roi=NR, seed=seed)
+    def step(seed):
+        batch = synth.synth_batch(B, cfg, S=128, num_imgs=NI, num_roi=NR, seed=seed)
         opt.zero_grad(set_to_none=True)
         loss, _ = O.fcmf_step_loss(P, cfg, batch, NI, NR, training=True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_([p for p in P.values() if p.grad is not None], 1.0)
         opt.step()
-    step(1, 1)                       # untimed warm-up (allocator, thread pool)
+    step(1)                          # untimed warm-up (allocator, thread pool)
+    times = []
+    for i in range(TIMED):
+        t0 = time.perf_counter()
+        step(2 + i)
+        times.append(time.perf_counter() - t0)
+    mean = sum(times) / len(times)
+    return dict(value=round(B / mean, 4), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                cpu=cpu_model(), host_cpu_count=os.cpu_count(), torch_threads=torch.get_num_threads(),
+                step_seconds=[round(t, 2) for t in times],
+                sample=f"config C0 (B=4 reviews x 6 aspects, seq128, 7x(49+36), fp32, dropout on, clip+AdamW): "
+                       f"1 warm-up + {TIMED} timed steps, mean {mean:.1f} s/step")
+
+
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 counter passes (tools/pmc_traffic.py) --
+    PMC counters cannot be read from inside this process.  The file carries the sha256 of the gemm.hip it was
+    measured with: a stale measurement (kernel source changed since) is reported as null, never as a number."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            doc = json.load(f)
+        with open(os.path.join(PKG, "csrc", "gemm.hip"), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()
+        if doc.get("gemm_hip_sha256") != sha:
+            return None, os.path.basename(files[-1]) + " (stale: gemm.hip changed since it was measured)"
+        return doc["kernels"].get(kernel, {}).get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
+def gemm_roofline(trace):
+    per = {}
+    for name, flops, ms in trace:
+        e = per.setdefault(name, [0, 0.0, 0.0])
+        e[0] += 1; e[1] += flops; e[2] += ms
+    mf = {k: v for k, v in per.items() if k.startswith("gemm_bf16_")}   # the bf16 MFMA kernels (tile256 / tile192 / 128x128)
+    if not mf:
+        return None
+    dom = max(mf, key=lambda k: mf[k][2])
+    n, fl, ms = mf[dom]
+    tot_fl, tot_ms = sum(v[1] for v in mf.values()), sum(v[2] for v in mf.values())
+    ach = fl / (ms * 1e-3) / 1e12
+    traffic, src = committed_traffic(dom)
+    return dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_source=src, launches=n,
+                avg_launch_ms=round(ms / n, 4), flops_per_launch=fl / n,
+                all_bf16_gemms=dict(launches=sum(v[0] for v in mf.values()), achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                                    ms_per_step=round(tot_ms, 3)),
+                per_kernel={k: dict(launches=v[0], tflops=round(v[1] / (v[2] * 1e-3) / 1e12, 1), ms=round(v[2], 3))
+                            for k, v in sorted(per.items(), key=lambda kv: -kv[1][2])})
+
+
+def timed_loop(step, args, world, dev, trace=True):
+    """W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs; MAX over ranks"""
+    from fcmf_framework import ops
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    step(B, 2)
+    out = None
+    for i in range(args.steps):
+        if trace and i == args.steps - 1:
+            ops.gemm_trace_begin()       # HIP events around every GEMM launch of the last timed step
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     dt = time.perf_counter() - t0
-    return dict(value=round(B / dt, 4), unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 step of config C0 (B=4 reviews x 6 aspects, seq128, 7x(49+36), fp32, dropout on, "
-                       f"clip+AdamW) after a B=1 warm-up; {dt:.1f} s; host cpu_count={os.cpu_count()}")
+    tr = ops.gemm_trace_end() if trace else []
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    return dt, tr, out
+
+
+# ---------------------------------------------------------------------------------------
+def run_fcmf(args, rank, world, dev):
+    import synthetic_data as synth
+    from fcmf_framework import ops
+    from fcmf_framework.dp import GradArena, GradReducer
+    from fcmf_framework.fcmf_multimodal import FCMF
+    from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup
+    from fcmf_framework.roberta import RobertaConfig, RobertaModel
+
+    S, NI, NR, A, B = 128, 7, 36, 6, args.batch
+    torch.manual_seed(42)
+    hf = tempfile.mkdtemp(prefix="hf_")
+    RobertaModel(RobertaConfig(**BASE_CFG)).save_pretrained(hf)
+    model = FCMF(hf, num_labels=4, num_imgs=NI, num_roi=NR).to(dev)
+    model.train(not args.no_dropout)
+    ops.manual_seed(42 + rank)
+    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    opt = FusedAdamW(param_groups(model), lr=7e-4)
+    sched = get_linear_schedule_with_warmup(opt, int(0.1 * 1000), 1000)
+    red = arena = None
+    if world > 1 or args.arena:
+        live = [p for n, p in model.named_parameters() if "bert.cell.pooler" not in n]     # the pooler never gets a gradient
+        arena = GradArena(live)
+        if world > 1:
+            red = GradReducer(arena)
+            red.broadcast_parameters(0)
+    host = synth.synth_batch(B, BASE_CFG, S=S, num_imgs=NI, num_roi=NR, num_aspects=A, seed=42 + rank)
+    batch = {k: v.to(dev) for k, v in host.items()}
+
+    def step():
+        if arena is not None:
+            arena.zero()
+        else:
+            opt.zero_grad(set_to_none=True)
+        logits = model.forward_aspects(batch["input_ids"], batch["visual_embeds_att"], batch["roi_embeds_att"],
+                                       batch["roi_coors"], batch["token_type_ids"], batch["attention_mask"],
+                                       batch["added_attention_mask"])
+        loss = model.loss_aspects(logits, batch["labels"])
+        loss.backward()
+        if red is not None:
+            red.finish()
+        opt.step(max_grad_norm=1.0)
+        sched.step()
+        return loss
+
+    dt, trace, loss = timed_loop(step, args, world, dev)
+    comm = red.stats() if red is not None else None
+    if rank != 0:
+        return None
+    # host -> HBM copy of one batch from pinned memory (never part of `value`: inputs are resident before the timed region)
+    pinned = {k: v.pin_memory() for k, v in host.items()}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        tmp = {k: v.to(dev, non_blocking=True) for k, v in pinned.items()}
+    torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t0) / 3 * 1e3
+    del tmp
+    ms_step = dt / args.steps * 1e3
+    out = {
+        "metric": "train samples/sec (fwd+bwd+step) FCMF seq128x36ROI",
+        "value": round(world * B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (seeded batch, random-init weights)",
+        "config": {"workload": "FCMF-base fine-tune step, BASELINE configs[1]: batch 64 reviews x 6 aspects per GPU, "
+                               "seq 128, 7 images x (49 patches + 36 ROIs), precomputed ResNet-152 features, dropout "
+                               + ("off" if args.no_dropout else "0.1") + ", clip 1.0 + 4-group AdamW + linear schedule",
+                   "global_batch": world * B, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
+                   "sample_unit": "1 review = 6 aspect forwards",
+                   "dense_flops_per_sample_fwd_bwd": algorithmic_flops_per_sample(BASE_CFG, S, NI, 49, NR, A)},
+        "loss": round(float(loss.item()), 4),
+        "h2d_ms_per_batch": round(h2d_ms, 2),
+        "value_with_h2d": round(world * B / ((ms_step + h2d_ms) * 1e-3), 2),
+        "roofline": gemm_roofline(trace),
+    }
+    if comm is not None:
+        out["dp"] = comm
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    return out
+
+
+def run_iaog(args, rank, world, dev):
+    """IAOG pre-training step (run_pretraining_fcmf.py:295-337): encoder (1 'aspect') + 12-block decoder + tied 64001-wide
+    vocabulary projection + CE(ignore_index) + clip + 2-group AdamW"""
+    import synthetic_data as synth
+    from fcmf_framework import ops
+    from fcmf_framework.dp import GradArena, GradReducer
+    from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq
+    from fcmf_framework.optimization import FusedAdamW
+    from fcmf_framework.roberta import RobertaConfig, RobertaModel
+    cfg = BASE_CFG
+    V, NI, NR, B, S, Ld = cfg["vocab_size"], 7, 4, args.batch, 128, args.dec_len
+    hf = tempfile.mkdtemp(prefix="hf_")
+    torch.manual_seed(42)
+    RobertaModel(RobertaConfig(**cfg)).save_pretrained(hf)
+    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    ops.manual_seed(42 + rank)
+    model = FCMFSeq2Seq(V, 20, hf, NI, NR, 1.0)
+    model.decoder.embedding = torch.nn.Embedding(V, model.decoder.num_hiddens)       # run_pretraining_fcmf.py:189
+    model = model.to(dev).train(not args.no_dropout)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    opt = FusedAdamW([{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 1e-5},
+                      {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}], lr=3e-5)
+    red = arena = None
+    if world > 1:
+        arena = GradArena([p for n, p in named if "bert.cell.pooler" not in n])
+        red = GradReducer(arena)
+        red.broadcast_parameters(0)
+    b = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, num_aspects=1, seed=3 + rank, coord_dtype=torch.float32)
+    b = {k: v.to(dev) for k, v in b.items()}
+    dec = torch.randint(3, V, (B, Ld), generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    lab = torch.roll(dec, -1, dims=1)
+    lab[:, -1] = -100
+
+    def step():
+        if arena is not None:
+            arena.zero()
+        else:
+            opt.zero_grad(set_to_none=True)
+        loss = model.forward_loss(b["input_ids"][:, 0], dec, lab, b["visual_embeds_att"], b["roi_embeds_att"], b["roi_coors"],
+                                  b["token_type_ids"][:, 0], b["attention_mask"][:, 0], b["added_attention_mask"][:, 0])
+        loss.backward()
+        if red is not None:
+            red.finish()
+        opt.step(max_grad_norm=1.0)
+        return loss
+
+    dt, trace, loss = timed_loop(step, args, world, dev)
+    if rank != 0:
+        return None
+    return {
+        "metric": "IAOG pre-train samples/sec (fwd+bwd+step) FCMF-base seq128", "value": round(world * B * args.steps / dt, 2),
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic (seeded batch, random-init weights)",
+        "config": {"workload": f"IAOG seq2seq pre-training step (BASELINE configs[3] geometry per GPU): batch {B}, seq 128, "
+                               f"7 images x (49 patches + {NR} ROIs), decoder length {Ld}, vocabulary {V}, fused vocabulary "
+                               "projection + CE(ignore_index=-100), clip 1.0 + 2-group AdamW(wd 1e-5)",
+                   "global_batch": world * B, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}"},
+        "loss": round(float(loss.item()), 4), "roofline": gemm_roofline(trace),
+    }
+
+
+def run_resnet(args, rank, world, dev):
+    """ResNet-152 feature extractor (run_multimodal_fcmf.py:449-460): crops/s of the batched, grouped-BatchNorm trunk in
+    train() mode; one 'step' = the image pass of one batch (NI call groups of B crops, 224 x 224)"""
+    import synthetic_data as synth
+    from fcmf_framework import ops
+    from fcmf_framework.resnet import resnet152
+    from fcmf_framework.resnet_utils import myResNetImg
+    B, NI = args.batch, 7
+    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    torch.manual_seed(42)
+    net = myResNetImg(resnet152().to(dev), False, dev).train()
+    x = synth.synth_crops(NI * B, 224, seed=rank).to(dev)
+
+    def step():
+        return net.forward_groups(x, NI, 7, tokens=True)
+
+    dt, trace, y = timed_loop(step, args, world, dev)
+    if rank != 0:
+        return None
+    crops = NI * B
+    gflop_per_crop = 2 * 11.51         # ResNet-152 forward at 224x224: 11.5 GMACs (He et al. 2016 table 1: 11.3e9 FLOPs = MACs)
+    ms = dt / args.steps * 1e3
+    return {
+        "metric": "ResNet-152 trunk crops/sec (forward, train-mode grouped BatchNorm)", "value": round(world * crops * args.steps / dt, 1),
+        "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic crops, random-init weights",
+        "config": {"workload": f"ResNet-152 trunk forward of one image pass: {NI} call groups x {B} crops of 224x224, NHWC GEMM "
+                               "convolutions (patch matrix for 7x7 / 3x3 / strided), per-group batch statistics, -> [B*NI, 49, 2048]",
+                   "crops_per_step": crops, "parallelism": f"dp{world}"},
+        "achieved_tflops_conv": round(crops * gflop_per_crop / ms, 1), "finite": bool(torch.isfinite(y).all().item()),
+        "roofline": gemm_roofline(trace),
+    }
 
 
 def main():
@@ -100,10 +368,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fcmf", choices=["fcmf", "iaog", "resnet"])
     ap.add_argument("--batch", type=int, default=64, help="reviews per GPU")
+    ap.add_argument("--dec_len", type=int, default=12, help="IAOG decoder length")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--arena", action="store_true", help="single GPU: also use the flat gradient arena (always on for --gpus > 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
@@ -124,113 +395,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
         else:
             dist.init_process_group(args.backend)
-
-    import synthetic_data as synth
-    from fcmf_framework import ops
-    from fcmf_framework.dp import GradReducer
-    from fcmf_framework.fcmf_multimodal import FCMF
-    from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup
-    from fcmf_framework.roberta import RobertaConfig, RobertaModel
-
-    S, NI, NR, A, B = 128, 7, 36, 6, args.batch
-    torch.manual_seed(42)
-    hf = tempfile.mkdtemp(prefix="hf_")
-    RobertaModel(RobertaConfig(**BASE_CFG)).save_pretrained(hf)
-    model = FCMF(hf, num_labels=4, num_imgs=NI, num_roi=NR).to(dev)
-    model.train(not args.no_dropout)
-    ops.manual_seed(42 + rank)
-    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    opt = FusedAdamW(param_groups(model), lr=7e-4)
-    total_steps = args.steps + args.warmup
-    sched = get_linear_schedule_with_warmup(opt, int(0.1 * 1000), 1000)
-    red = GradReducer([p for n, p in model.named_parameters() if "bert.cell.pooler" not in n]) if world > 1 else None
-    if red is not None:
-        red.broadcast_parameters(0)
-    batch = {k: v.to(dev) for k, v in synth.synth_batch(B, BASE_CFG, S=S, num_imgs=NI, num_roi=NR, num_aspects=A,
-                                                        seed=42 + rank).items()}
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        logits = model.forward_aspects(batch["input_ids"], batch["visual_embeds_att"], batch["roi_embeds_att"],
-                                       batch["roi_coors"], batch["token_type_ids"], batch["attention_mask"],
-                                       batch["added_attention_mask"])
-        loss = model.loss_aspects(logits, batch["labels"])
-        loss.backward()
-        if red is not None:
-            red.finish()
-        opt.step(max_grad_norm=1.0)
-        sched.step()
-        return loss
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == args.steps - 1:
-            ops.gemm_trace_begin()       # HIP events around every GEMM launch of the last timed step
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    trace = ops.gemm_trace_end()
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    if rank != 0:
+    out = {"fcmf": run_fcmf, "iaog": run_iaog, "resnet": run_resnet}[args.workload](args, rank, world, dev)
+    if rank == 0:
         if world > 1:
-            dist.destroy_process_group()
-        return
-
-    # ---- roofline of the dominant kernel family ------------------------------------------
-    per = {}
-    for name, flops, ms in trace:
-        e = per.setdefault(name, [0, 0.0, 0.0])
-        e[0] += 1; e[1] += flops; e[2] += ms
-    mf = {k: v for k, v in per.items() if k.startswith("gemm_bf16_")}   # the bf16 MFMA kernels (tile256 / tile192 / 128x128)
-    roof = None
-    if mf:
-        dom = max(mf, key=lambda k: mf[k][2])
-        n, fl, ms = mf[dom]
-        tot_fl, tot_ms = sum(v[1] for v in mf.values()), sum(v[2] for v in mf.values())
-        ach = fl / (ms * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from
-        # the committed rocprofv3 counter passes of this same command (tools/pmc_traffic.py -> profiles/), else null
-        traffic = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-        except (OSError, ValueError, KeyError):
-            traffic = None
-        roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, launches=n,
-                    avg_launch_ms=round(ms / n, 4), flops_per_launch=fl / n,
-                    all_bf16_gemms=dict(launches=sum(v[0] for v in mf.values()), achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
-                                        ms_per_step=round(tot_ms, 3)),
-                    per_kernel={k: dict(launches=v[0], tflops=round(v[1] / (v[2] * 1e-3) / 1e12, 1), ms=round(v[2], 3))
-                                for k, v in sorted(per.items(), key=lambda kv: -kv[1][2])})
-    ms_step = dt / args.steps * 1e3
-    out = {
-        "metric": "train samples/sec (fwd+bwd+step) FCMF seq128x36ROI",
-        "value": round(world * B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (seeded batch, random-init weights)",
-        "config": {"workload": "FCMF-base fine-tune step, BASELINE configs[1]: batch 64 reviews x 6 aspects per GPU, "
-                               "seq 128, 7 images x (49 patches + 36 ROIs), precomputed ResNet-152 features, dropout "
-                               + ("off" if args.no_dropout else "0.1") + ", clip 1.0 + 4-group AdamW + linear schedule",
-                   "global_batch": world * B, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
-                   "sample_unit": "1 review = 6 aspect forwards",
-                   "dense_flops_per_sample_fwd_bwd": algorithmic_flops_per_sample(BASE_CFG, S, NI, 49, NR, A, False)},
-        "loss": round(float(loss.item()), 4),
-        "roofline": roof,
-    }
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline("")
-    print(json.dumps(out))
+            out["dp_backend"] = dist.get_backend()
+            out["dp_ranks_seen"] = dist.get_world_size()
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

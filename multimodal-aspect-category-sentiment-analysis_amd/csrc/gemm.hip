@@ -354,18 +354,6 @@ __device__ __forceinline__ unsigned dma_voffset_t(int piece, int lane, int64_t l
 
 template <int V> struct IntTag { static constexpr int value = V; };
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate).  Only the counts the
-// persistent kernel can ask for are listed; anything else waits for everything (always safe).
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-#define FCMF_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    FCMF_VMC(12) FCMF_VMC(15) FCMF_VMC(16) FCMF_VMC(18) FCMF_VMC(20) FCMF_VMC(24) FCMF_VMC(27) FCMF_VMC(28) FCMF_VMC(30)
-    FCMF_VMC(32) FCMF_VMC(35) FCMF_VMC(36) FCMF_VMC(38) FCMF_VMC(40)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef FCMF_VMC
-}
-
 // 8 consecutive outputs of one row <-> four packed-f32 pairs
 __device__ __forceinline__ void load8f(const float* q, f32x2 (&v)[4]) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(q), b = *reinterpret_cast<const f32x4*>(q + 4);
@@ -458,6 +446,9 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   };
   // DMA of k-tile t of item w into ring stage s
   auto issue = [&](const Item& w, const Src& src, int t, int s) {
+#ifdef FCMF_GEMM_ABLATE_DMA      // diagnostic build: no global->LDS traffic (the ring holds whatever it held)
+    return;
+#endif
     char* st = stage_at(s);
     const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
 #pragma unroll
@@ -480,11 +471,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   };
   constexpr bool PREFETCH = sizeof(TC) == 2;   // bf16 epilogue leaves the ring alone -> next item's tiles 0, 1 fly under it
   bool pre = false;
-  // Vector-memory operations (epilogue stores) this wave issued AFTER it put the current item's tiles 0..2 in flight.
-  // The counter retires in issue order, so those stores are YOUNGER than the tiles: the landing waits of tiles 0..2
-  // may leave them outstanding (the store tail of an epilogue then drains under the next item's first k-tiles
-  // instead of in front of its first barrier: 3-5 us per 256x256 GELU tile).  Any lower bound is safe.
-  int st_pending = 0;
 
   for (int item = slot; item < p.total_items; item += nblk) {
   const Item w = decode(item);
@@ -501,10 +487,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   auto wait_landed = [&](int t, auto per_tile) {
     constexpr int PT = decltype(per_tile)::value;   // DMAs per k-tile of this wave: 4, or 3 for waves 4-7 of the 192-row tile
     const int younger = nkt - 1 - t;
-    if (t < 3 && st_pending) {
-      wait_vmcnt_dyn((younger >= 2 ? 2 : younger) * PT + st_pending);
-      return;
-    }
     if (younger >= 2) { if (PT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else if (younger == 1) { if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -527,6 +509,13 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     for (int f = 0; f < MI; ++f) fa[f] = frag_a(st, f);
   };
   auto mma = [&]() {
+#ifdef FCMF_GEMM_ABLATE_MMA      // diagnostic build: feed only (fragments stay live, no matrix instructions)
+#pragma unroll
+    for (int fi = 0; fi < MI; ++fi) asm volatile("" :: "v"(fa[fi]));
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) asm volatile("" :: "v"(fb[fj]));
+    return;
+#endif
 #pragma unroll
     for (int fi = 0; fi < MI; ++fi)
 #pragma unroll
@@ -740,7 +729,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       }
       write_out(o1, rC, p.colsum != nullptr);
     }
-    st_pending = pre ? 4 * NRND * ((EPI == FCMF_EPI_GELU && p.aux != nullptr) ? 2 : 1) : 0;   // buffer stores of the rounds above
     if (p.colsum) {
       // a lane owns 8 fixed columns for the rows it visited; lanes that share (lane & 7) share the columns
 #pragma unroll

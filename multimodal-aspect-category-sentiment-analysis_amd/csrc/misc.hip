@@ -50,6 +50,99 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(const T* __restrict__ log
   }
 }
 
+// ---- cross entropy over a WIDE class axis (IAOG: the 64001-entry vocabulary, run_pretraining_fcmf.py:322-324):
+// one workgroup per row, 16-byte loads, one online (max, sum-exp) pass; the backward may run IN PLACE
+// (dlogits == logits: every element is read and written by the same thread).
+template <typename T> struct XVec;
+template <> struct XVec<float> { static constexpr int N = 4; typedef f32x4 type; };
+template <> struct XVec<bf16_t> { static constexpr int N = 8; typedef bf16x8 type; };
+
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+  const float mn = fmaxf(m, m2);
+  s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+  m = mn;
+}
+
+// block-wide (max, sum exp(x - max)) of lr[0..C): every thread returns the same pair
+template <typename T>
+__device__ __forceinline__ void row_softmax_stats(const T* __restrict__ lr, int C, bool vec, float& m_out, float& s_out) {
+  constexpr int VN = XVec<T>::N;
+  typedef typename XVec<T>::type vec_t;
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float m = -INFINITY, s = 0.f;
+  const int Cv = vec ? (C / VN) * VN : 0;
+  for (int c = tid * VN; c < Cv; c += 256 * VN) {
+    const vec_t v = *reinterpret_cast<const vec_t*>(lr + c);
+    float x[VN], mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { x[e] = (float)v[e]; mx = fmaxf(mx, x[e]); }
+    const float mn = fmaxf(m, mx);
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc += __expf(x[e] - mn);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + acc;
+    m = mn;
+  }
+  for (int c = Cv + tid; c < C; c += 256) online_merge(m, s, to_f32<T>(lr[c]), 1.f);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) online_merge(m, s, __shfl_xor(m, o, 64), __shfl_xor(s, o, 64));
+  if (lane == 0) { red[0][w] = m; red[1][w] = s; }
+  __syncthreads();
+  m = red[0][0]; s = red[1][0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) online_merge(m, s, red[0][k], red[1][k]);
+  m_out = m; s_out = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xent_fwd_wide_kernel(const T* __restrict__ logits, int64_t ld,
+                                                            const int64_t* __restrict__ labels, float* __restrict__ loss_rows,
+                                                            float* __restrict__ nvalid, int C, int64_t ignore_index, int vec) {
+  const int row = blockIdx.x;
+  const int64_t lab = labels[row];
+  if (lab == ignore_index) { if (threadIdx.x == 0) loss_rows[row] = 0.f; return; }
+  const T* lr = logits + (int64_t)row * ld;
+  float m, s;
+  row_softmax_stats<T>(lr, C, vec != 0, m, s);
+  if (threadIdx.x == 0) {
+    loss_rows[row] = (m + __logf(s)) - to_f32<T>(lr[lab]);
+    if (nvalid) atomicAdd(nvalid, 1.0f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xent_bwd_wide_kernel(const T* logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                            T* dlogits, int64_t ldd, const float* __restrict__ scale_ptr,
+                                                            float extra, int C, int64_t ignore_index, int vec) {
+  constexpr int VN = XVec<T>::N;
+  typedef typename XVec<T>::type vec_t;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int64_t lab = labels[row];
+  T* dr = dlogits + (int64_t)row * ldd;
+  const int Cv = vec ? (C / VN) * VN : 0;
+  if (lab == ignore_index) {
+    vec_t z;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) z[e] = from_f32<T>(0.f);
+    for (int c = tid * VN; c < Cv; c += 256 * VN) *reinterpret_cast<vec_t*>(dr + c) = z;
+    for (int c = Cv + tid; c < C; c += 256) dr[c] = from_f32<T>(0.f);
+    return;
+  }
+  const T* lr = logits + (int64_t)row * ld;
+  float m, s;
+  row_softmax_stats<T>(lr, C, vec != 0, m, s);
+  const float sc = (scale_ptr ? *scale_ptr : 1.0f) * extra, inv = sc / s;
+  for (int c = tid * VN; c < Cv; c += 256 * VN) {
+    const vec_t v = *reinterpret_cast<const vec_t*>(lr + c);
+    vec_t o;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) o[e] = from_f32<T>(__expf((float)v[e] - m) * inv - ((c + e) == lab ? sc : 0.f));
+    *reinterpret_cast<vec_t*>(dr + c) = o;
+  }
+  for (int c = Cv + tid; c < C; c += 256) dr[c] = from_f32<T>(__expf(to_f32<T>(lr[c]) - m) * inv - (c == lab ? sc : 0.f));
+}
+
 // ---- elementwise ---------------------------------------------------------------------------
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
@@ -221,6 +314,15 @@ extern "C" int fcmf_xent_fwd(const void* logits, int64_t ld, const int64_t* labe
   if (!logits || !labels || !loss_rows || n < 0 || C <= 0) return FCMF_ERR_ARG;
   if (n == 0) return FCMF_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (C >= 1024) {     // wide class axis: one workgroup per row
+    const int es = dtype == FCMF_F32 ? 4 : 2;
+    const int vec = ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) && ((ld * es) % 16 == 0);
+    if (dtype == FCMF_F32) hipLaunchKernelGGL((xent_fwd_wide_kernel<float>), dim3(n), dim3(256), 0, st, (const float*)logits, ld, labels, loss_rows, nvalid, C, ignore_index, vec);
+    else if (dtype == FCMF_BF16) hipLaunchKernelGGL((xent_fwd_wide_kernel<bf16_t>), dim3(n), dim3(256), 0, st, (const bf16_t*)logits, ld, labels, loss_rows, nvalid, C, ignore_index, vec);
+    else return FCMF_ERR_UNSUPPORTED;
+    FCMF_CHECK_LAUNCH();
+    return FCMF_OK;
+  }
   dim3 grid((n + 3) / 4);
   if (dtype == FCMF_F32) hipLaunchKernelGGL((xent_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)logits, ld, labels, loss_rows, nvalid, n, C, ignore_index);
   else if (dtype == FCMF_BF16) hipLaunchKernelGGL((xent_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)logits, ld, labels, loss_rows, nvalid, n, C, ignore_index);
@@ -235,6 +337,16 @@ extern "C" int fcmf_xent_bwd(const void* logits, int64_t ld, const int64_t* labe
   if (!logits || !labels || !dlogits || n < 0 || C <= 0) return FCMF_ERR_ARG;
   if (n == 0) return FCMF_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (C >= 1024) {
+    const int es = dtype == FCMF_F32 ? 4 : 2;
+    const int vec = (((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0) &&
+                    ((ld * es) % 16 == 0) && ((ldd * es) % 16 == 0);
+    if (dtype == FCMF_F32) hipLaunchKernelGGL((xent_bwd_wide_kernel<float>), dim3(n), dim3(256), 0, st, (const float*)logits, ld, labels, (float*)dlogits, ldd, scale_ptr, extra_scale, C, ignore_index, vec);
+    else if (dtype == FCMF_BF16) hipLaunchKernelGGL((xent_bwd_wide_kernel<bf16_t>), dim3(n), dim3(256), 0, st, (const bf16_t*)logits, ld, labels, (bf16_t*)dlogits, ldd, scale_ptr, extra_scale, C, ignore_index, vec);
+    else return FCMF_ERR_UNSUPPORTED;
+    FCMF_CHECK_LAUNCH();
+    return FCMF_OK;
+  }
   dim3 grid((n + 3) / 4);
   if (dtype == FCMF_F32) hipLaunchKernelGGL((xent_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)logits, ld, labels, (float*)dlogits, ldd, scale_ptr, extra_scale, n, C, ignore_index);
   else if (dtype == FCMF_BF16) hipLaunchKernelGGL((xent_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)logits, ld, labels, (bf16_t*)dlogits, ldd, scale_ptr, extra_scale, n, C, ignore_index);

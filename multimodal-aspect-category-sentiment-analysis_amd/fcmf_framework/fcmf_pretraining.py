@@ -140,8 +140,8 @@ class FCMFSeq2Seq(nn.Module):
             self.decoder.embedding.weight = self.encoder.bert.cell.embeddings.word_embeddings.weight
         self.decoder.dense.weight = self.decoder.embedding.weight
 
-    def forward(self, enc_X, dec_X, visual_embeds_att, roi_embeds_att, roi_coors=None, token_type_ids=None,
-                attention_mask=None, added_attention_mask=None, source_valid_len=None, is_train=True):
+    def _decoder_state(self, enc_X, visual_embeds_att, roi_embeds_att, roi_coors, token_type_ids, attention_mask,
+                       added_attention_mask):
         enc_output, enc_attentions = self.encoder(enc_X, visual_embeds_att, roi_embeds_att, roi_coors,
                                                   token_type_ids, attention_mask, added_attention_mask)
         num_visual_tokens = self.num_imgs * 2
@@ -149,11 +149,25 @@ class FCMFSeq2Seq(nn.Module):
         text_mask = attention_mask[:, :current_text_len]
         vis_mask = torch.ones((text_mask.size(0), num_visual_tokens), device=text_mask.device, dtype=text_mask.dtype)
         combined_mask = torch.cat((text_mask, vis_mask), dim=1)     # 2-D => tril rule in the decoder (:184-199)
-        dec_state = [enc_output, combined_mask, [None] * self.decoder.num_blks]
+        return [enc_output, combined_mask, [None] * self.decoder.num_blks], enc_attentions
+
+    def forward(self, enc_X, dec_X, visual_embeds_att, roi_embeds_att, roi_coors=None, token_type_ids=None,
+                attention_mask=None, added_attention_mask=None, source_valid_len=None, is_train=True):
+        dec_state, enc_attentions = self._decoder_state(enc_X, visual_embeds_att, roi_embeds_att, roi_coors,
+                                                        token_type_ids, attention_mask, added_attention_mask)
         logits = self.decoder(dec_X, dec_state, is_train=is_train)
         if not is_train:
             return logits, enc_attentions
         return logits
+
+    def forward_loss(self, enc_X, dec_X, labels, visual_embeds_att, roi_embeds_att, roi_coors=None, token_type_ids=None,
+                     attention_mask=None, added_attention_mask=None, ignore_index=-100):
+        """the training step's `CrossEntropyLoss(ignore_index=-100)(forward(...).permute(0, 2, 1), labels)`
+        (run_pretraining_fcmf.py:309-324) as one call: same value, the 64001-wide logits stay inside the fused
+        projection + loss node (ops.VocabCrossEntropyFn)"""
+        dec_state, _ = self._decoder_state(enc_X, visual_embeds_att, roi_embeds_att, roi_coors, token_type_ids,
+                                           attention_mask, added_attention_mask)
+        return self.decoder.loss(dec_X, dec_state, labels, ignore_index=ignore_index)
 
     def _init_weights(self, module):
         if isinstance(module, nn.Linear):

@@ -212,7 +212,8 @@ class IAOGDecoder(nn.Module):
     def init_state(self, enc_outputs, enc_valid_lens):
         return [enc_outputs, enc_valid_lens, [None] * self.num_blks]
 
-    def forward(self, X, state, enc_attention_mask=None, is_train=True):
+    def hidden_states(self, X, state, enc_attention_mask=None, is_train=True):
+        """the decoder stack up to (not including) the vocabulary projection: [B, Ld, H]"""
         X = _ScaledEmbedding.apply(X, self.embedding.weight, math.sqrt(self.num_hiddens), ops.compute_dtype())
         X = self.pos_encoding(X)
         self._attention_weights = [[None] * len(self.blks) for _ in range(2)]
@@ -220,7 +221,17 @@ class IAOGDecoder(nn.Module):
             X, state = blk(X, state, enc_attention_mask=enc_attention_mask, is_train=is_train)
             self._attention_weights[0][i] = blk.attention1.attention_weights
             self._attention_weights[1][i] = blk.attention2.attention_weights
+        return X
+
+    def forward(self, X, state, enc_attention_mask=None, is_train=True):
+        X = self.hidden_states(X, state, enc_attention_mask, is_train)
         return ops.vocab_linear(X, self.dense.weight, self.dense.bias)
+
+    def loss(self, X, state, labels, enc_attention_mask=None, ignore_index=-100):
+        """CrossEntropyLoss(ignore_index)(forward(X).permute(0, 2, 1), labels) (run_pretraining_fcmf.py:322-324) with
+        the vocabulary projection and the loss fused: the [B, Ld, V] logits are never handed out"""
+        X = self.hidden_states(X, state, enc_attention_mask, True)
+        return ops.vocab_cross_entropy(X, self.dense.weight, self.dense.bias, labels, ignore_index)
 
     @property
     def attention_weights(self):

@@ -419,6 +419,72 @@ def vocab_linear(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias, None)
 
 
+class VocabCrossEntropyFn(torch.autograd.Function):
+    """loss = CrossEntropy(x W^T + b, labels; ignore_index) in ONE autograd node: the IAOG head
+    (mm_modeling.py:662 logits -> run_pretraining_fcmf.py:322-324 loss).  The [rows, V] logits live only inside the
+    node, in a column-padded buffer the MFMA kernels can write (64001 -> 64032 columns); the loss kernel reads it with
+    its row stride, the logit gradient overwrites it IN PLACE and feeds the dX / dW GEMMs directly -- no compaction
+    copy to the reference's [B, Ld, V] shape, no padded re-copy and no zero-filled gradient buffer in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, labels, ignore_index):
+        x2 = _rows(x)
+        V, K = weight.shape
+        M = x2.shape[0]
+        if x2.dtype == torch.bfloat16 and V % VOCAB_PAD != 0:
+            w = shadows.padded(weight)                     # [Vp, K] bf16, rows >= V zero
+        else:
+            w = as_compute(weight, x2.dtype)
+        Vp = w.shape[0]
+        bp = None
+        if bias is not None:
+            bp = bias.detach()
+            if Vp != V:
+                bp = torch.zeros(Vp, dtype=torch.float32, device=x2.device)
+                bp[:V] = bias.detach()
+        logits = torch.empty((M, Vp), dtype=x2.dtype, device=x2.device)
+        gemm(x2, w, logits, M, Vp, K, _ld(x2), K, Vp, 0, 0, bias=bp)
+        lb = labels.reshape(-1).contiguous()
+        rows = torch.empty(M, dtype=torch.float32, device=x2.device)
+        nvalid = torch.zeros(1, dtype=torch.float32, device=x2.device)
+        H.check(H.lib().fcmf_xent_fwd(H.ptr(logits), Vp, H.ptr(lb), H.ptr(rows), H.ptr(nvalid), M, V, ignore_index,
+                                      H.dt(logits), H.stream()), "fcmf_xent_fwd")
+        ctx.save_for_backward(x2, weight, logits, lb, nvalid)
+        ctx.cfg = (ignore_index, bias is not None, x.shape)
+        return rows.sum() / nvalid[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, weight, logits, lb, nvalid = ctx.saved_tensors
+        ignore_index, has_bias, xshape = ctx.cfg
+        V, K = weight.shape
+        M, Vp = logits.shape
+        w = shadows.padded(weight) if (x2.dtype == torch.bfloat16 and V % VOCAB_PAD != 0) else as_compute(weight, x2.dtype)
+        scale = (g.float() / nvalid[0]).reshape(1).contiguous()
+        d = logits                                          # in place: the node owns the buffer
+        H.check(H.lib().fcmf_xent_bwd(H.ptr(logits), Vp, H.ptr(lb), H.ptr(d), Vp, H.ptr(scale), 1.0, M, V, ignore_index,
+                                      H.dt(logits), H.stream()), "fcmf_xent_bwd")
+        if Vp != V:
+            d[:, V:].zero_()                                # the padding logits (= bias 0) must not leak into dX / dW
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
+            gemm(d, w, dx, M, K, Vp, Vp, K, K, 0, 1)
+            dx = dx.view(xshape)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((Vp, K), dtype=torch.float32, device=x2.device)
+            gemm(d, x2, dwp, Vp, K, M, Vp, _ld(x2), K, 1, 1, acc=True)
+            dw = dwp[:V]
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum(d, M, Vp, Vp)[:V]
+        return dx, dw, db, None, None
+
+
+def vocab_cross_entropy(x, weight, bias, labels, ignore_index=-100):
+    """mean CE of the vocabulary projection of x over the non-ignored positions (torch CrossEntropyLoss semantics)"""
+    return VocabCrossEntropyFn.apply(x, weight, bias, labels, int(ignore_index))
+
+
 class FFNFn(torch.autograd.Function):
     """y = gelu_erf(x W1^T + b1) W2^T + b2   (BertIntermediate + BertOutput.dense,
     mm_modeling.py:305-314,320; decoder PositionWiseFFN :558-565).  GELU is the epilogue of the

@@ -488,6 +488,66 @@ def test_cross_entropy(dev, dtype):
     assert rel_err(lg.grad, lr.grad) < tol * 2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,ld", [(64001, 64032), (64001, 64001), (2048, 2048), (1500, 1504)])
+def test_cross_entropy_wide_vocabulary(dev, dtype, C, ld):
+    """the IAOG loss over a wide, possibly ragged class axis read with a row stride (the column-padded logits buffer):
+    16-byte path (aligned rows) and scalar path (odd row stride), ignored rows, and the in-place backward"""
+    ops, H = _ops()
+    n = 21
+    buf = _rand((n, ld), dev, dtype, 3.0, seed=1)
+    lg = buf[:, :C]
+    lb = torch.randint(0, C, (n,), generator=torch.Generator().manual_seed(2))
+    lb[3] = -100
+    lb[7] = C - 1
+    lbd = lb.to(dev)
+    rows = torch.empty(n, dtype=torch.float32, device=dev)
+    nvalid = torch.zeros(1, dtype=torch.float32, device=dev)
+    H.check(H.lib().fcmf_xent_fwd(H.ptr(buf), ld, H.ptr(lbd), H.ptr(rows), H.ptr(nvalid), n, C, -100, H.dt(buf), H.stream()), "xent_fwd")
+    lr = lg.detach().float().cpu().requires_grad_(True)
+    ref_rows = F.cross_entropy(lr, lb, ignore_index=-100, reduction="none")
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert int(nvalid.item()) == n - 1
+    assert max_err(rows, ref_rows.detach()) < tol * 12
+    ref_rows.sum().backward()
+    scale = torch.full((1,), 0.5, dtype=torch.float32, device=dev)
+    d = torch.full_like(buf, 7.0)
+    H.check(H.lib().fcmf_xent_bwd(H.ptr(buf), ld, H.ptr(lbd), H.ptr(d), ld, H.ptr(scale), 2.0, n, C, -100, H.dt(buf), H.stream()), "xent_bwd")
+    assert max_err(d[:, :C], lr.grad) < (1e-6 if dtype == torch.float32 else 4e-3)
+    assert (d[:, C:] == 7.0).all()                              # columns past C are not touched
+    keep = buf.clone()
+    H.check(H.lib().fcmf_xent_bwd(H.ptr(buf), ld, H.ptr(lbd), H.ptr(buf), ld, H.ptr(scale), 2.0, n, C, -100, H.dt(buf), H.stream()), "xent_bwd")
+    assert torch.equal(buf[:, :C], d[:, :C]) and torch.equal(buf[:, C:], keep[:, C:])     # in place == out of place
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vocab_cross_entropy_fused_node(dev, dtype):
+    """ops.vocab_cross_entropy == cross_entropy(vocab_linear(x)) (value and all three gradients), ragged vocabulary"""
+    ops, H = _ops()
+    ops.set_compute_dtype(dtype)
+    ops.shadows.clear()
+    try:
+        V, K, B, Ld = 1999, 64, 3, 5
+        w = _rand((V, K), dev, scale=0.3, seed=1).requires_grad_(True)
+        b = _rand((V,), dev, scale=0.1, seed=2).requires_grad_(True)
+        x = _rand((B, Ld, K), dev, dtype, seed=3).requires_grad_(True)
+        lb = torch.randint(0, V, (B, Ld), generator=torch.Generator().manual_seed(4))
+        lb[:, -1] = -100
+        loss = ops.vocab_cross_entropy(x, w, b, lb.to(dev))
+        loss.backward()
+        xr, wr, br = (a.detach().float().cpu().requires_grad_(True) for a in (x, w, b))
+        wc = wr if dtype == torch.float32 else wr.bfloat16().float()
+        ref = F.cross_entropy(F.linear(xr, wc, br).permute(0, 2, 1), lb, ignore_index=-100)
+        ref.backward()
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert abs(loss.item() - ref.item()) < tol * abs(ref.item())
+        for got, want in ((x.grad, xr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
+            assert rel_err(got, want) < (1e-4 if dtype == torch.float32 else 3e-2)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+        ops.shadows.clear()
+
+
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_and_ffn_autograd(dev, dtype):

@@ -396,7 +396,13 @@ def test_iaog_tiny_matches_reference(dev, B):
     assert max_err(logits[:, :, ::8], torch.from_numpy(z[t + "logits"])) < 1e-4
     loss = ops.cross_entropy(logits, torch.from_numpy(z[t + "labels"]).to(dev), ignore_index=-100)
     assert abs(loss.item() - float(z[t + "loss"])) < 1e-4
-    loss.backward()
+    # the fused projection + loss node gives the same loss and (checked below) the same gradients
+    loss_fused = model.forward_loss(batch["input_ids"][:, 0], dec, torch.from_numpy(z[t + "labels"]).to(dev),
+                                    batch["visual_embeds_att"], batch["roi_embeds_att"], batch["roi_coors"],
+                                    batch["token_type_ids"][:, 0], batch["attention_mask"][:, 0],
+                                    batch["added_attention_mask"][:, 0])
+    assert abs(loss_fused.item() - float(z[t + "loss"])) < 1e-4
+    (loss if B == 3 else loss_fused).backward()
     named = dict(model.named_parameters())
     names = [str(n) for n in z[t + "grad_names"]]
     gn = dict(zip(names, z[t + "grad_norms"]))
