@@ -229,15 +229,32 @@ def _post_bwd(dy, c, saved, wo, w1, w2, g1, g2, p, seeds, G, side):
     return dc, dz1
 
 
-def _grad_arena(device, Hd, I, with_qkv):
-    """all float32 gradient buffers of one layer from ONE zero fill"""
+def _grad_arena(device, Hd, I, with_qkv, params=None):
+    """all float32 gradient buffers of one layer: the parameters' slices of the step's flat gradient arena when one is
+    active (dp.GradArena: zeroed once per step), else views of ONE zero fill.  params: name -> Parameter (or the
+    [q, k, v] list for "wqkv" / "bqkv")."""
     sizes = [("wo", (Hd, Hd)), ("w1", (I, Hd)), ("w2", (Hd, I)), ("bo", (Hd,)), ("b1", (I,)), ("b2", (Hd,)),
              ("g1", (Hd,)), ("be1", (Hd,)), ("g2", (Hd,)), ("be2", (Hd,))]
     if with_qkv:
         sizes = [("wqkv", (3 * Hd, Hd)), ("bqkv", (3 * Hd,))] + sizes
+    arena = ops.grad_arena() if params is not None else None
+    out = {}
+    if arena is not None:
+        for n, s in sizes:
+            q = params.get(n)
+            v = None
+            if isinstance(q, (list, tuple)):
+                v = arena.take_block(q)
+            elif q is not None:
+                v = arena.take(q)
+            if v is not None:
+                out[n] = v.view(s)
+        sizes = [(n, s) for n, s in sizes if n not in out]
+        if not sizes:
+            return out
     total = sum(math.prod(s) for _, s in sizes)
     flat = torch.zeros(total, dtype=torch.float32, device=device)
-    out, off = {}, 0
+    off = 0
     for n, s in sizes:
         k = math.prod(s)
         out[n] = flat[off:off + k].view(s)
@@ -255,15 +272,16 @@ class PostAttentionFn(torch.autograd.Function):
         if r2.stride(1) != 1:
             r2 = r2.contiguous()
         y, saved = _post_fwd(c2, r2, ops._ld(r2), wo, bo, g1, be1, w1, b1, w2, b2, g2, be2, eps, p, (seed0, seed1))
-        ctx.save_for_backward(c2, wo, w1, w2, g1, g2, *saved)
+        ctx.save_for_backward(c2, wo, w1, w2, g1, g2, bo, be1, b1, b2, be2, *saved)
         ctx.cfg = (p, seed0, seed1, c.shape, res.shape)
         return y.view(c.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        c2, wo, w1, w2, g1, g2, *saved = ctx.saved_tensors
+        c2, wo, w1, w2, g1, g2, bo, be1, b1, b2, be2, *saved = ctx.saved_tensors
         p, s0, s1, cshape, rshape = ctx.cfg
-        G = _grad_arena(c2.device, c2.shape[1], w1.shape[0], False)
+        G = _grad_arena(c2.device, c2.shape[1], w1.shape[0], False,
+                        dict(wo=wo, w1=w1, w2=w2, bo=bo, b1=b1, b2=b2, g1=g1, be1=be1, g2=g2, be2=be2))
         side = _SideGemms(c2.device)
         dc, dres = _post_bwd(dy.reshape(c2.shape).contiguous(), c2, saved, wo, w1, w2, g1, g2, p, (s0, s1), G, side)
         side.join()
@@ -290,17 +308,19 @@ class SelfLayerFn(torch.autograd.Function):
         mk = None if mask is None else mask.contiguous().float()
         c, lse = self_attention_fwd(qkv, mk, G_, T, Hd, heads, p_a, seed_a)
         y, saved = _post_fwd(c, x2, Hd, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2, eps, p_h, (seed0, seed1))
-        ctx.save_for_backward(x2, mk, qkv, c, lse, wq, wk, wv, wo, w1, w2, g1, g2, *saved)
+        ctx.save_for_backward(x2, mk, qkv, c, lse, wq, wk, wv, wo, w1, w2, g1, g2, bq, bk, bv, bo, be1, b1, b2, be2, *saved)
         ctx.cfg = (heads, p_h, p_a, seed_a, seed0, seed1, x.shape)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, mk, qkv, c, lse, wq, wk, wv, wo, w1, w2, g1, g2, *saved = ctx.saved_tensors
+        x2, mk, qkv, c, lse, wq, wk, wv, wo, w1, w2, g1, g2, bq, bk, bv, bo, be1, b1, b2, be2, *saved = ctx.saved_tensors
         heads, p_h, p_a, seed_a, s0, s1, xshape = ctx.cfg
         G_, T, Hd = xshape
         M, dt = G_ * T, x2.dtype
-        G = _grad_arena(x2.device, Hd, w1.shape[0], True)
+        G = _grad_arena(x2.device, Hd, w1.shape[0], True,
+                        dict(wqkv=[wq, wk, wv], bqkv=[bq, bk, bv], wo=wo, w1=w1, w2=w2, bo=bo, b1=b1, b2=b2, g1=g1, be1=be1,
+                             g2=g2, be2=be2))
         side = _SideGemms(x2.device)
         dc, dz1 = _post_bwd(dy.reshape(M, Hd).contiguous(), c, saved, wo, w1, w2, g1, g2, p_h, (s0, s1), G, side)
         dqkv = self_attention_bwd(qkv, mk, c, lse, dc, G_, T, Hd, heads, p_a, seed_a)

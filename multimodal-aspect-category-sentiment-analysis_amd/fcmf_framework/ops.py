@@ -144,6 +144,42 @@ class _Shadows:
 
 shadows = _Shadows()
 
+# --------------------------------------------------------------------------------------
+# flat gradient arena (dp.GradArena): weight-gradient buffers come out of the parameter's slice of ONE zeroed
+# buffer when an arena is active, so that autograd adopts the slice as p.grad (no copy) and a step needs one memset
+# --------------------------------------------------------------------------------------
+_grad_arena = None
+
+
+def set_grad_arena(arena):
+    global _grad_arena
+    _grad_arena = arena
+
+
+def grad_arena():
+    return _grad_arena
+
+
+def alloc_grad(param, shape=None):
+    """zero-initialised float32 buffer for the gradient of `param` (viewed as `shape`): the parameter's arena
+    slice if an arena is active and the slice is still unclaimed in this step, else a fresh zero tensor"""
+    a = _grad_arena
+    if a is not None and param is not None:
+        v = a.take(param)
+        if v is not None:
+            return v if shape is None else v.view(shape)
+    return torch.zeros(tuple(param.shape) if shape is None else shape, dtype=torch.float32, device=param.device)
+
+
+def alloc_grad_block(params, shape):
+    """one zero-initialised buffer covering the gradients of `params` back to back (fused q|k|v)"""
+    a = _grad_arena
+    if a is not None:
+        v = a.take_block(params)
+        if v is not None:
+            return v.view(shape)
+    return torch.zeros(shape, dtype=torch.float32, device=params[0].device)
+
 
 def as_compute(w, dtype):
     """parameter as seen by a kernel computing in `dtype`"""
@@ -275,7 +311,9 @@ def _linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=True, dx_epi=H.EPI
         dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
         gemm_dx(dy, master, w, dx, M, K, N, aux=dx_aux, epi=dx_epi)
     if need_dw:
-        dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+        dw = alloc_grad(master, (N, K)) if (master is not None and master.dtype == torch.float32 and master.is_contiguous()
+                                              and tuple(master.shape) == (N, K)) else \
+            torch.zeros((N, K), dtype=torch.float32, device=dy.device)
         gemm(dy, x, dw, N, K, M, N, _ld(x), K, 1, 1, acc=True)
     if need_db:
         db = colsum(dy, M, N, N)
@@ -625,6 +663,7 @@ class EmbedLNFn(torch.autograd.Function):
                                           ntok, Hd, eps, p, seed, H.dt(y), H.stream()), "fcmf_embed_ln_fwd")
         ctx.save_for_backward(ids, pos, tt, z, gamma, mean, rstd)
         ctx.p, ctx.seed, ctx.pad_id = p, seed, pad_id
+        ctx.word = word if (word.dtype == torch.float32 and word.is_contiguous()) else None   # (the Parameter: arena lookup)
         ctx.shapes = (word.shape, ptab.shape, ttab.shape)
         return y.view(*ids.shape, Hd)
 
@@ -644,7 +683,7 @@ class EmbedLNFn(torch.autograd.Function):
         H.check(L.fcmf_add_ln_bwd(H.ptr(d), H.ptr(z), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(dz), 0, H.ptr(dg),
                                   H.ptr(db), 0, H.ptr(ln_workspace(ntok, Hd, z.device)), ntok, Hd, 0.0, 0, H.dt(z), H.stream()), "fcmf_add_ln_bwd")
         ws, ps, ts = ctx.shapes
-        dword = torch.zeros(ws, dtype=torch.float32, device=z.device)
+        dword = alloc_grad(ctx.word, ws) if ctx.word is not None else torch.zeros(ws, dtype=torch.float32, device=z.device)
         dpos = torch.zeros(ps, dtype=torch.float32, device=z.device)
         dtt = torch.zeros(ts, dtype=torch.float32, device=z.device)
         two_d = ids.dim() == 2 and pos.is_contiguous()

@@ -31,7 +31,7 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 from fcmf_framework import ops  # noqa: E402
-from fcmf_framework.dp import GradReducer  # noqa: E402
+from fcmf_framework.dp import GradArena, GradReducer  # noqa: E402
 from fcmf_framework.fcmf_multimodal import FCMF  # noqa: E402
 from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup  # noqa: E402
 
@@ -90,6 +90,11 @@ def build_parser():
                         help="train on N seeded synthetic batches per epoch (precomputed features); no dataset needed")
     parser.add_argument('--precomputed_features', action='store_true',
                         help="the dataset yields ResNet-152 features instead of pixels (BASELINE.json configs)")
+    parser.add_argument('--synthetic_pixels', type=int, default=0,
+                        help="with --synthetic_steps: batches carry SIZE x SIZE pixel crops and the ResNet-152 trunk runs inside "
+                             "the step (reference :449-460); 0 = precomputed features")
+    parser.add_argument('--resnet_checkpoint', default=None, type=str,
+                        help="torchvision resnet152 state dict (.pth, loaded with weights_only=True) for the HIP trunk")
     return parser
 
 
@@ -114,9 +119,10 @@ class SyntheticBatches:
     """seeded stand-in for DataLoader(MACSADataset): the reference's 9-tuple layout
     (vimacsa_dataset.py:202) with precomputed features in place of pixel tensors"""
 
-    def __init__(self, cfg, steps, batch, S, num_imgs, num_rois, num_aspects, seed):
+    def __init__(self, cfg, steps, batch, S, num_imgs, num_rois, num_aspects, seed, pixels=0):
         self.cfg, self.steps, self.batch, self.S = cfg, steps, batch, S
         self.ni, self.nr, self.na, self.seed = num_imgs, num_rois, num_aspects, seed
+        self.pixels = pixels
 
     def __len__(self):
         return self.steps
@@ -126,7 +132,13 @@ class SyntheticBatches:
         for i in range(self.steps):
             b = synth.synth_batch(self.batch, self.cfg, S=self.S, num_imgs=self.ni, num_roi=self.nr,
                                   num_aspects=self.na, seed=self.seed + i)
-            yield (b["visual_embeds_att"], b["roi_embeds_att"], b["roi_coors"], b["input_ids"], b["token_type_ids"],
+            vis, roi = b["visual_embeds_att"], b["roi_embeds_att"]
+            if self.pixels:          # the reference's pixel layout: float32 images, float64 ROI crops (vimacsa_dataset.py:175-199)
+                n = self.batch * self.ni
+                vis = synth.synth_crops(n, self.pixels, seed=self.seed + i).view(self.batch, self.ni, 3, self.pixels, self.pixels)
+                roi = synth.synth_crops(n * self.nr, self.pixels, seed=self.seed + i + 7919).view(
+                    self.batch, self.ni, self.nr, 3, self.pixels, self.pixels).double()
+            yield (vis, roi, b["roi_coors"], b["input_ids"], b["token_type_ids"],
                    b["attention_mask"], b["added_attention_mask"], b["labels"], None)
 
 
@@ -168,7 +180,12 @@ def main(argv=None):
         cfgd = dict(vocab_size=cfg.vocab_size, pad_token_id=cfg.pad_token_id)
         train_loader = SyntheticBatches(cfgd, args.synthetic_steps, args.train_batch_size,
                                         min(args.max_seq_length, 128, cfg.max_position_embeddings - 2),
-                                        args.num_imgs, args.num_rois, len(ASPECT), args.seed + 1000 * rank)
+                                        args.num_imgs, args.num_rois, len(ASPECT), args.seed + 1000 * rank,
+                                        pixels=args.synthetic_pixels)
+        if args.do_eval:
+            dev_loader = SyntheticBatches(cfgd, max(1, args.synthetic_steps // 2), args.eval_batch_size,
+                                          min(args.max_seq_length, 128, cfg.max_position_embeddings - 2),
+                                          args.num_imgs, args.num_rois, len(ASPECT), args.seed + 77, pixels=args.synthetic_pixels)
     elif args.do_train or args.do_eval:
         # real data: the reference's host-side producer (tokenizer, pandas, MACSADataset, torchvision ResNet-152)
         from transformers import AutoTokenizer
@@ -189,11 +206,27 @@ def main(argv=None):
         sampler = DistributedSampler(train_ds) if world > 1 else RandomSampler(train_ds)     # shard ONCE
         train_loader = DataLoader(train_ds, sampler=sampler, batch_size=args.train_batch_size)
         dev_loader = DataLoader(dev_ds, sampler=SequentialSampler(dev_ds), batch_size=args.eval_batch_size)
-        if not args.precomputed_features:
-            from torchvision.models import resnet152, ResNet152_Weights
-            from fcmf_framework.resnet_utils import myResNetImg, myResNetRoI
-            resnet_img = myResNetImg(resnet152(weights=ResNet152_Weights.IMAGENET1K_V2).to(device), args.fine_tune_cnn, device)
-            resnet_roi = myResNetRoI(resnet152(weights=ResNet152_Weights.IMAGENET1K_V2).to(device), args.fine_tune_cnn, device)
+    pixels = (args.synthetic_steps > 0 and args.synthetic_pixels > 0) or \
+             (args.synthetic_steps <= 0 and (args.do_train or args.do_eval) and not args.precomputed_features)
+    if pixels:
+        # the ResNet-152 feature extractor of the step (reference :224-227) on the HIP trunk.  Weights: a local
+        # torchvision checkpoint (--resnet_checkpoint), else torchvision's IMAGENET1K_V2 if torchvision is importable
+        # and has them cached, else random initialisation (logged): nothing is ever downloaded.
+        from fcmf_framework.resnet import resnet152
+        from fcmf_framework.resnet_utils import myResNetImg, myResNetRoI
+
+        def trunk():
+            if args.resnet_checkpoint:
+                return resnet152(weights=torch.load(args.resnet_checkpoint, map_location='cpu', weights_only=True))
+            try:
+                from torchvision.models import resnet152 as tv_resnet152, ResNet152_Weights
+                return tv_resnet152(weights=ResNet152_Weights.IMAGENET1K_V2)       # adopted by the HIP trunk (from_module)
+            except Exception as e:                                              # not installed / weights not cached
+                if master:
+                    logger.info("ResNet-152: no checkpoint given and torchvision weights unavailable (%s): random init", type(e).__name__)
+                return resnet152()
+        resnet_img = myResNetImg(trunk().to(device), args.fine_tune_cnn, device)
+        resnet_roi = myResNetRoI(trunk().to(device), args.fine_tune_cnn, device)
 
     model = model.to(device)
     if args.freeze_encoder:
@@ -203,9 +236,11 @@ def main(argv=None):
     steps_per_epoch = len(train_loader) if train_loader is not None else 0
     num_train_steps = int(steps_per_epoch / args.gradient_accumulation_steps * args.num_train_epochs)
     scheduler = get_linear_schedule_with_warmup(optimizer, int(num_train_steps * args.warmup_proportion), num_train_steps)
+    # gradients live in one flat arena (one memset per step; buckets of it are all-reduced in place under --ddp)
+    arena = GradArena.for_model(model)
     reducer = None
     if world > 1:
-        reducer = GradReducer([p for n, p in model.named_parameters() if p.requires_grad and "bert.cell.pooler" not in n])
+        reducer = GradReducer(arena)
         reducer.broadcast_parameters(0)
 
     start_epoch, max_f1 = 0, 0.0
@@ -223,19 +258,21 @@ def main(argv=None):
         ops.shadows.clear()
 
     def features(t_img, roi_img):
-        """pixels -> ResNet-152 features (reference :449-460) unless the batch already holds features"""
+        """pixels -> ResNet-152 features (reference :449-460) unless the batch already holds features: the reference's
+        num_imgs + num_imgs * num_rois trunk calls as two batched passes with per-call BatchNorm statistics"""
         if resnet_img is None:
             return t_img, roi_img
-        enc_img = [resnet_img(t_img[:, i]).view(-1, 2048, 49).permute(0, 2, 1) for i in range(args.num_imgs)]
-        enc_roi = [torch.stack([resnet_roi(roi_img[:, i, r].float()) for r in range(args.num_rois)], dim=1) for i in range(args.num_imgs)]
-        return torch.stack(enc_img, 1), torch.stack(enc_roi, 1)
+        from fcmf_framework.resnet_utils import extract_features
+        return extract_features(resnet_img, resnet_roi, t_img, roi_img)
 
     if args.do_train:
         for epoch in range(start_epoch, int(args.num_train_epochs)):
             if world > 1 and hasattr(train_loader, 'sampler') and hasattr(train_loader.sampler, 'set_epoch'):
                 train_loader.sampler.set_epoch(epoch)
             model.train()
-            optimizer.zero_grad(set_to_none=True)
+            if resnet_img is not None:
+                resnet_img.train(); resnet_roi.train()                # reference :431 (BatchNorm in batch-statistics mode)
+            arena.zero()
             for step, batch in enumerate(train_loader):
                 batch = tuple(t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
                 t_img, roi_img, roi_coors, ids, tts, ams, added, labels, _ = batch
@@ -254,7 +291,7 @@ def main(argv=None):
                         reducer.finish()
                     optimizer.step(max_grad_norm=1.0)                 # clip_grad_norm_(1.0) fused into AdamW
                     scheduler.step()
-                    optimizer.zero_grad(set_to_none=True)
+                    arena.zero()
                 if master and step % 10 == 0:
                     logger.info("epoch %d step %d loss %.4f", epoch, step, loss.item() * args.gradient_accumulation_steps)
             if master:
@@ -262,6 +299,8 @@ def main(argv=None):
                             optimizer.param_groups[0]['lr'], optimizer.param_groups[2]['lr'])
             f1 = 0.0
             if dev_loader is not None and master:
+                if resnet_img is not None:
+                    resnet_img.eval(); resnet_roi.eval()              # reference :502
                 f1 = evaluate(model, dev_loader, device, features, len(ASPECT), logger)
             if world > 1:
                 torch.distributed.barrier()
@@ -270,6 +309,7 @@ def main(argv=None):
                     max_f1 = f1
                     save_model(f'{args.output_dir}/seed_{args.seed}_fcmf_model_best.pth', model, optimizer, scheduler, epoch, max_f1)
                 save_model(f'{args.output_dir}/seed_{args.seed}_fcmf_model_last.pth', model, optimizer, scheduler, epoch, max_f1)
+    arena.deactivate()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -24,7 +24,7 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 from fcmf_framework import ops  # noqa: E402
-from fcmf_framework.dp import GradReducer  # noqa: E402
+from fcmf_framework.dp import GradArena, GradReducer  # noqa: E402
 from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq  # noqa: E402
 from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup  # noqa: E402
 
@@ -132,9 +132,10 @@ def main(argv=None):
 
     num_train_steps = int(steps_per_epoch / args.gradient_accumulation_steps * args.num_train_epochs)
     scheduler = get_linear_schedule_with_warmup(optimizer, int(num_train_steps * args.warmup_proportion), num_train_steps)
+    arena = GradArena.for_model(model)
     reducer = None
     if world > 1:
-        reducer = GradReducer([p for n, p in named if "bert.cell.pooler" not in n])
+        reducer = GradReducer(arena)
         reducer.broadcast_parameters(0)
     start_epoch = 0
     if args.resume_from_checkpoint and os.path.isfile(args.resume_from_checkpoint):
@@ -147,13 +148,11 @@ def main(argv=None):
     if args.do_train:
         for epoch in range(start_epoch, int(args.num_train_epochs)):
             model.train()
-            optimizer.zero_grad(set_to_none=True)
+            arena.zero()
             for step, batch in enumerate(make_loader()):
                 vis, roi, coors, enc_X, tt, am, added, dec_X, labels = (t.to(device) for t in batch)
-                logits = model(enc_X=enc_X, dec_X=dec_X, visual_embeds_att=vis, roi_embeds_att=roi, roi_coors=coors,
-                               token_type_ids=tt, attention_mask=am, added_attention_mask=added, source_valid_len=None,
-                               is_train=True)
-                loss = ops.cross_entropy(logits, labels, ignore_index=-100)                 # reference :322-324
+                # model(...) -> logits -> CrossEntropyLoss(ignore_index=-100) (reference :309-324) as one fused call
+                loss = model.forward_loss(enc_X, dec_X, labels, vis, roi, coors, tt, am, added, ignore_index=-100)
                 if args.gradient_accumulation_steps > 1:
                     loss = loss / args.gradient_accumulation_steps
                 boundary = (step + 1) % args.gradient_accumulation_steps == 0
@@ -165,13 +164,14 @@ def main(argv=None):
                         reducer.finish()
                     optimizer.step(max_grad_norm=1.0)
                     scheduler.step()
-                    optimizer.zero_grad(set_to_none=True)
+                    arena.zero()
                 if master and step % 10 == 0:
                     logger.info("epoch %d step %d loss %.4f", epoch, step, loss.item() * args.gradient_accumulation_steps)
             if world > 1:
                 torch.distributed.barrier()
             if master:
                 save_model(f'{args.output_dir}/seed_{args.seed}_iaog_model_last.pth', model, optimizer, scheduler, epoch)
+    arena.deactivate()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -31,8 +31,7 @@ def _worker(rank, world, port, q):
     y = torch.randn(8, 3, generator=g)
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
     for step in range(2):                             # two steps: the reducer must re-arm itself
-        for p in params:
-            p.grad = None
+        red.arena.zero()
         ((net(xs) - ys) ** 2).mean().backward()
         red.finish()
     grads = [p.grad.clone() for p in net.parameters()]
@@ -43,6 +42,62 @@ def _worker(rank, world, port, q):
     err = max((a - p.grad).abs().max().item() for a, p in zip(grads, net.parameters()))
     q.put((rank, err, len(red.buckets), all(p.grad is None for p in dead.parameters())))
     dist.destroy_process_group()
+
+
+def _accum_worker(rank, world, port, q):
+    """gradient accumulation: the exchange happens only on the boundary micro-step (`enabled`), on gradients that
+    live in ONE flat arena and are all-reduced in place"""
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fcmf_framework.dp import GradArena, GradReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 3))
+    params = list(net.parameters())
+    arena = GradArena(params)
+    red = GradReducer(arena, bucket_mb=0.0005)
+    red.broadcast_parameters(0)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(16, 16, generator=g)
+    y = torch.randn(16, 3, generator=g)
+    launches = []
+    orig = red._launch
+    red._launch = lambda bi: (None if red._launched[bi] else launches.append((micro[0], bi)), orig(bi))[1]
+    micro = [0]
+    ok_views = True
+    for step in range(2):
+        arena.zero()
+        for m in range(2):                            # two micro-steps of 4 samples per rank
+            micro[0] = m
+            lo = rank * 8 + m * 4
+            red.enabled = (m == 1)
+            (((net(x[lo:lo + 4]) - y[lo:lo + 4]) ** 2).mean() / 2).backward()
+        red.finish()
+        ok_views = ok_views and all(p.grad.data_ptr() == arena.view[id(p)].data_ptr() for p in params)
+    grads = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    ((net(x) - y) ** 2).mean().backward()
+    err = max((a - p.grad).abs().max().item() for a, p in zip(grads, params))
+    q.put((rank, err, all(m == 1 for m, _ in launches), len(launches), len(red.buckets), ok_views))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_accumulation_boundary_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, boundary_only, nlaunch, nb, ok_views in res:
+        assert err < 1e-6, (rank, err)
+        assert boundary_only and nlaunch == 2 * nb and nb > 1      # one in-place collective per bucket per optimizer step
+        assert ok_views                                            # p.grad IS the arena slice after the exchange
 
 
 def test_grad_reducer_two_ranks_gloo():

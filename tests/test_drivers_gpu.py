@@ -33,6 +33,26 @@ def test_finetune_driver_synthetic(tmp_path, dev):
     ops.set_compute_dtype(torch.float32)
 
 
+def test_finetune_driver_eval_path_and_resnet_in_the_loop(tmp_path, dev, caplog):
+    """--do_eval runs the dev-set evaluation (no-grad forward, argmax, macro-F1 per aspect: reference :500-552) after the
+    epoch; --synthetic_pixels puts the ResNet-152 trunk inside the step (reference :449-460): pixel crops in, the two
+    batched trunk passes, then the FCMF step on the features they produce"""
+    import logging
+    import run_multimodal_fcmf as drv
+    hf = make_hf_dir(synth.TINY_CFG)
+    out = str(tmp_path / "ev")
+    with caplog.at_level(logging.INFO, logger="fcmf"):
+        drv.main(["--output_dir", out, "--pretrained_hf_model", hf, "--do_train", "--do_eval", "--num_imgs", "2", "--num_rois", "2",
+                  "--train_batch_size", "2", "--eval_batch_size", "2", "--gradient_accumulation_steps", "1", "--synthetic_steps", "2",
+                  "--synthetic_pixels", "64", "--max_seq_length", "16", "--seed", "4", "--num_train_epochs", "1", "--bf16"])
+    from fcmf_framework import ops
+    ops.set_compute_dtype(torch.float32)
+    log = open(os.path.join(out, "training_fcmf.log")).read()
+    assert "Dev macro-F1 per aspect" in log
+    ck = torch.load(os.path.join(out, "seed_4_fcmf_model_last.pth"), map_location="cpu", weights_only=True)
+    assert 0.0 <= ck["best_score"] <= 1.0 and ck["epoch"] == 0
+
+
 def test_pretraining_driver_synthetic(tmp_path, dev):
     import run_pretraining_fcmf as drv
     hf = make_hf_dir(synth.TINY_CFG)
