@@ -115,8 +115,8 @@ int fcmf_attn_small_fwd(const fcmf_attn_desc* desc /*host*/, void* out, float* l
  *   dk1/dv1 [G, T1, heads*d];   dk2/dv2 [G, R, T2, heads*d] (indexed by g, NOT g/group_div: the
  *       caller sums groups that share a private segment);
  *   dbias (float32, may be NULL) [G, heads, R, T1+T2].
- * When v1 == k1 (IAOG) pass dv1 = NULL: dk1 receives both terms.  Limits: T1+T2 <= 256, T2 <= 128,
- * d <= 128. */
+ * When v1 == k1 (IAOG) pass dv1 = NULL: dk1 receives both terms.  Limits: T1+T2 <= 512, T2 <= 128,
+ * d <= 128 (FCMF-large: 256 text keys + 100 ROI keys in the shared mm_attention layer). */
 int fcmf_attn_small_bwd(const fcmf_attn_desc* desc /*host*/, const void* out, const void* dout,
                         const float* lse, void* dq, void* dk1, void* dv1, void* dk2, void* dv2,
                         float* dbias, void* stream);

@@ -11,7 +11,7 @@
 // and the IAOG decoder; the bf16 text-encoder attention runs on attn_mfma.hip instead.
 #include "common.h"
 
-constexpr int AS_MAXT = 256;   // T1 + T2 <= 256 (keys per lane: 4)
+constexpr int AS_MAXT = 512;   // T1 + T2 <= 512 (forward: KPL = 4 or 8 keys per lane; FCMF-large fuses 256 text + 100 ROI keys)
 constexpr int AS_MAXD = 128;   // head dim <= 128 (two elements per lane)
 constexpr int AS_NT1 = 32;     // shared keys per backward chunk <= 128: a wave accumulates keys w + 4n, n < 32
 
@@ -138,8 +138,9 @@ __device__ __forceinline__ bool private_rows_vectorisable(const fcmf_attn_desc& 
          (reinterpret_cast<uintptr_t>(a.k2) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.v2) & 15) == 0;
 }
 
-template <typename TT>
+template <typename TT, int KPL>
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
+  constexpr int PMAX = 64 * KPL;          // keys a wave's probability row can hold
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const fcmf_attn_desc& a = P.a;
   const int d = a.d, T1 = a.T1, T2 = a.T2, T = T1 + T2, RB = P.RB;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
   TT* K1s = reinterpret_cast<TT*>(sm);
   TT* V1s = K1s + T1 * dp;
   float* Qs = sm + P.KVF;               // [RB][d] (KVF = floats taken by the two K/V images)
-  float* ps = Qs + RB * d;              // [4][AS_MAXT] probability row of each wave
+  float* ps = Qs + RB * d;              // [4][PMAX] probability row of each wave
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
   const int hin = a.head_quirk ? (int)(((int64_t)h * a.G + g) % a.heads) : h;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
     stage_rows<TT, TT>(V1s, dp, reinterpret_cast<const TT*>(a.v1) + (int64_t)g * a.k1_sg + hin * d, a.k1_st, T1, d, w, lane);
   }
   const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
-  float* p = ps + w * AS_MAXT;
+  float* p = ps + w * PMAX;
   const bool vec2 = private_rows_vectorisable<TT>(a);
   for (int rb0 = 0; rb0 < a.R; rb0 += RB) {
     const int nr = min(RB, a.R - rb0);
@@ -172,9 +173,9 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
     for (int rl = w; rl < nr; rl += 4) {
       const int r = rb0 + rl;
       const float* q = Qs + rl * d;
-      float sc[4];
+      float sc[KPL];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < KPL; ++n) {
         const int t = lane + 64 * n;
         float accv = 0.f;
         if (t < T1) {
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
       }
       float m = -INFINITY;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < KPL; ++n) {
         const int t = lane + 64 * n;
         float s = -INFINITY;
         if (t < T) {
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
       m = wave_max(m);
       float sum = 0.f;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < KPL; ++n) {
         const int t = lane + 64 * n;
         const float e = t < T ? __expf(sc[n] - m) : 0.f;
         sc[n] = e;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
       sum = wave_sum(sum);
       const float inv = 1.0f / sum;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < KPL; ++n) {
         const int t = lane + 64 * n;
         if (t < T) {
           float pv = sc[n] * inv;
@@ -486,22 +487,23 @@ extern "C" int fcmf_attn_small_fwd(const fcmf_attn_desc* desc, void* out, float*
   P.a = *desc; P.out = out; P.lse = lse;
   const size_t esz = desc->dtype == FCMF_F32 ? 4 : 2;
   P.KVF = (int)((2 * (size_t)desc->T1 * (desc->d + 16 / esz) * esz + 15) / 16 * 4);   // K and V images, rounded to 16 B, in floats
-  const size_t base = sizeof(float) * ((size_t)P.KVF + 4 * AS_MAXT);
+  const int kpl = desc->T1 + desc->T2 <= 256 ? 4 : 8;     // keys per lane of the forward
+  const size_t base = sizeof(float) * ((size_t)P.KVF + 4 * 64 * kpl);
   const size_t per_row = sizeof(float) * (size_t)desc->d;
   P.RB = rows_per_block(desc->R, base, per_row);
   if (P.RB <= 0) return FCMF_ERR_UNSUPPORTED;
   const size_t smem = base + (size_t)P.RB * per_row;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(desc->G * desc->heads);
-  if (desc->dtype == FCMF_F32) {
-    auto k = attn_small_fwd_kernel<float>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, P);
-  } else {
-    auto k = attn_small_fwd_kernel<bf16_t>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, P);
-  }
+#define FCMF_ATTN_FWD(TT, KPL)                                                                                             \
+  do {                                                                                                                     \
+    auto k = attn_small_fwd_kernel<TT, KPL>;                                                                               \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
+    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, P);                                                                   \
+  } while (0)
+  if (desc->dtype == FCMF_F32) { if (kpl == 4) FCMF_ATTN_FWD(float, 4); else FCMF_ATTN_FWD(float, 8); }
+  else { if (kpl == 4) FCMF_ATTN_FWD(bf16_t, 4); else FCMF_ATTN_FWD(bf16_t, 8); }
+#undef FCMF_ATTN_FWD
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }

@@ -40,7 +40,7 @@ def transformer_layer(layer, xq, xkv, add_mask, heads, eps, p_hidden, p_attn, tr
     """Full (unpruned) post-LN layer: xq [B,Tq,H] attends to xkv [B,Tk,H]; add_mask [B,Tk] float32.
     Self-attention (xq is xkv) runs as one fused node (fused.SelfLayerFn)."""
     sa = layer.attention.self
-    if xq is xkv and xq.dim() == 3 and xq.shape[1] <= 256 and xq.shape[2] // heads <= 128:
+    if xq is xkv and xq.dim() == 3 and xq.shape[1] <= 512 and xq.shape[2] // heads <= 128:
         from .fused import SelfLayerFn
         ao = layer.attention.output
         ph = float(p_hidden) if training else 0.0

@@ -66,6 +66,9 @@ def build_parser():
     p.add_argument('--synthetic_steps', type=int, default=0)
     p.add_argument('--synthetic_dec_len', type=int, default=12)
     p.add_argument('--vocab_size', type=int, default=0, help="decoder vocabulary (len(tokenizer) with real data)")
+    p.add_argument('--feature_cache_dir', default=None, type=str,
+                   help="precomputed ResNet-152 features of the training reviews (feature_cache.build); else pixels + the HIP trunk")
+    p.add_argument('--resnet_checkpoint', default=None, type=str, help="torchvision resnet152 state dict for the HIP trunk")
     return p
 
 
@@ -127,8 +130,48 @@ def main(argv=None):
         steps_per_epoch = args.synthetic_steps
         make_loader = batches
     else:
-        raise SystemExit("real-data IAOG pre-training needs the host-side producer (iaog_dataset.IAOGDataset + torchvision): "
-                         "SURVEY.md section 8(f) 'next'; use --synthetic_steps N for the kernel path")
+        # real data (reference :130-183): reviews with `iaog_labels`, one sample per (review, aspect); photos through the
+        # HIP ResNet-152 trunk inside the step, or a precomputed feature cache.  (The reference also runs underthesea's
+        # Vietnamese text normalisation over the comments; that host-side text cleaning is not part of this build --
+        # feed already-normalised JSON.)
+        import json
+        import pandas as pd
+        from torch.utils.data import DataLoader, DistributedSampler, RandomSampler
+        from iaog_dataset import IAOGDataset
+        train_data = pd.read_json(f'{args.pretrained_data_dir}/train_with_iaog.json')
+        if 'iaog_labels' not in train_data.columns:
+            raise ValueError("'iaog_labels' column not found in data. Check JSON file structure.")
+        roi_df = pd.read_csv(f"{args.data_dir}/roi_data.csv")
+        roi_df['file_name'] = roi_df['file_name'] + '.png'
+        with open(f'{args.data_dir}/resnet152_image_label.json') as f:
+            dict_image_aspect = json.load(f)
+        with open(f'{args.data_dir}/resnet152_roi_label.json') as f:
+            dict_roi_aspect = json.load(f)
+        cache = None
+        if args.feature_cache_dir:
+            from feature_cache import FeatureCache
+            cache = FeatureCache(args.feature_cache_dir)
+        train_ds = IAOGDataset(train_data, tokenizer, args.image_dir, roi_df, dict_image_aspect, dict_roi_aspect,
+                               args.num_imgs, args.num_rois, args.max_len_decoder, feature_cache=cache)
+        if len(train_ds) == 0:
+            raise SystemExit("train_dataset is empty: no 'sentiment_word#Aspect' labels in iaog_labels")
+        sampler = DistributedSampler(train_ds) if world > 1 else RandomSampler(train_ds)      # shard once
+        loader = DataLoader(train_ds, sampler=sampler, batch_size=args.train_batch_size)
+        extract = None
+        if cache is None:
+            from fcmf_framework.resnet import resnet152
+            from fcmf_framework.resnet_utils import extract_features, myResNetImg, myResNetRoI
+            sd = torch.load(args.resnet_checkpoint, map_location='cpu', weights_only=True) if args.resnet_checkpoint else None
+            r_img = myResNetImg(resnet152(weights=sd).to(device), args.fine_tune_cnn, device).train()
+            r_roi = myResNetRoI(resnet152(weights=sd).to(device), args.fine_tune_cnn, device).train()
+            extract = lambda a, b: extract_features(r_img, r_roi, a.to(device), b.to(device))
+
+        def batches():
+            for t_img, roi_img, coors, labels, dec, enc_ids, enc_type, enc_mask, added, _, _ in loader:
+                vis, roi = (t_img, roi_img) if extract is None else extract(t_img, roi_img)
+                yield (vis, roi, coors.float(), enc_ids, enc_type, enc_mask, added, dec, labels)
+        steps_per_epoch = len(loader)
+        make_loader = batches
 
     num_train_steps = int(steps_per_epoch / args.gradient_accumulation_steps * args.num_train_epochs)
     scheduler = get_linear_schedule_with_warmup(optimizer, int(num_train_steps * args.warmup_proportion), num_train_steps)

@@ -25,6 +25,14 @@ BASE_CFG = dict(vocab_size=64001, hidden_size=768, num_hidden_layers=12, num_att
                 attention_probs_dropout_prob=0.1)
 
 
+# FCMF-large (BASELINE.json configs[4]): XLM-R-large geometry; the vocabulary is kept at 64001 rows (the embedding table
+# is a gather, its row count does not change any kernel shape) so that the test model stays ~0.4 G parameters
+LARGE_CFG = dict(vocab_size=64001, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                 intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1,
+                 pad_token_id=1, layer_norm_eps=1e-5, hidden_dropout_prob=0.1,
+                 attention_probs_dropout_prob=0.1)
+
+
 def _layer_shapes(prefix, H, I, out):
     for n in ("query", "key", "value"):
         out[f"{prefix}.attention.self.{n}.weight"] = (H, H)
@@ -141,7 +149,7 @@ def synth_batch(B, cfg, S=128, num_imgs=7, num_roi=36, num_aspects=6, num_labels
             ids[b, a, 1:l - 1] = rng.integers(3, V, size=l - 2)
             ids[b, a, l - 1] = 2
     att = (ids != cfg["pad_token_id"]).astype(np.int64)
-    added = np.ones((B, num_aspects, S + 49), dtype=np.int64)
+    added = np.ones((B, num_aspects, S + max(49, num_roi)), dtype=np.int64)   # covers text + patches and text + ROIs
     vis = np.abs(rng.standard_normal((B, num_imgs, 49, feat_dim), dtype=np.float32)) * 0.5
     roi = np.abs(rng.standard_normal((B, num_imgs, num_roi, feat_dim), dtype=np.float32)) * 0.5
     xs = np.sort(rng.random((B, num_imgs, num_roi, 2)), axis=-1)

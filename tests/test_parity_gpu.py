@@ -357,6 +357,42 @@ def test_base_multimodal_layer_output_matches_reference(base, dev):
     assert (got - ref).abs().max().item() < 1e-3
 
 
+def test_fcmf_large_geometry_bf16_and_fp32(dev):
+    """BASELINE configs[4] geometry (XLM-R-large text encoder H1024 L24 heads16 I4096, seq 256, 100 ROIs per image: the
+    shared mm_attention layer attends over 256 + 100 = 356 keys, the text encoder over 256): one review, one aspect,
+    fp32 logits against the CPU oracle within 1e-3; bf16 logits within bf16 rounding of them; the bf16 training graph
+    produces finite gradients for every live parameter.  (fp8 GEMMs of that config are not built.)"""
+    cfg = synth.LARGE_CFG
+    NI, NR, S = 7, 100, 256
+    model, P = build_fcmf(cfg, NI, NR, dev)
+    model.eval()
+    batch = synth.synth_batch(1, cfg, S=S, num_imgs=NI, num_roi=NR, num_aspects=2, seed=9, min_len=200)
+    b = batch_to(batch, dev)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = O.fcmf_forward(P, cfg, batch["input_ids"][:, 0], batch["visual_embeds_att"], batch["roi_embeds_att"],
+                             batch["roi_coors"], batch["token_type_ids"][:, 0], batch["attention_mask"][:, 0],
+                             batch["added_attention_mask"][:, 0], NI, NR)
+    try:
+        _set(torch.float32)
+        with torch.no_grad():
+            l32 = _run_aspects(model, b)
+        assert max_err(l32[:, 0], ref) < 1e-3, max_err(l32[:, 0], ref)
+        _set(torch.bfloat16)
+        model.zero_grad(set_to_none=True)
+        l16 = _run_aspects(model, b)
+        assert max_err(l16, l32) < 6e-2, max_err(l16, l32)
+        model.loss_aspects(l16, b["labels"]).backward()
+        for n, p in model.named_parameters():
+            if "bert.cell.pooler" in n:
+                assert p.grad is None
+            else:
+                assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    finally:
+        _set(torch.float32)
+        model.zero_grad(set_to_none=True)
+
+
 def _iaog_model(dev, B):
     from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq
     from helpers import make_hf_dir
