@@ -209,6 +209,12 @@ int fcmf_xent_bwd(const void* logits, int64_t ld, const int64_t* labels, void* d
 int fcmf_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 /* dst (bfloat16 [cols, rows]) = transpose(src float32 [rows, cols]): transposed weight copies for the dX GEMMs */
 int fcmf_cast_transpose(const float* src, void* dst, int rows, int cols, void* stream);
+/* the same for many weights in ONE launch (all transposed copies go stale together at the optimizer step):
+ * src_ptrs / dst_ptrs: device int64 arrays of device addresses (float32 [rows_t, cols_t] -> bfloat16 [cols_t, rows_t]);
+ * dims: device int32 [ntensors][2] = (rows, cols); tile_desc: device int32 [ntiles][3] = (tensor, tile row, tile column),
+ * one 64x64 tile per workgroup. */
+int fcmf_multi_cast_transpose(const int64_t* src_ptrs, const int64_t* dst_ptrs, const int32_t* dims,
+                              const int32_t* tile_desc, int ntiles, void* stream);
 /* y = x * dropout_mask(seed) / (1-p) ; used for the classifier-head dropout
  * (fcmf_multimodal.py:49) and its backward (same call on dy). */
 int fcmf_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);

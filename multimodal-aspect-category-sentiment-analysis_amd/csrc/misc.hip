@@ -171,6 +171,29 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
   }
 }
 
+// the same for MANY weights in one launch (after an optimizer step every transposed copy is stale at once: 69 launches
+// of ~10 us each per step otherwise).  desc[b] = {tensor, tile row, tile column} of workgroup b.
+__global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const int64_t* __restrict__ src_ptrs, const int64_t* __restrict__ dst_ptrs,
+                                                                   const int32_t* __restrict__ dims, const int32_t* __restrict__ desc) {
+  __shared__ float tile[64][65];
+  const int t = desc[3 * blockIdx.x], r0 = desc[3 * blockIdx.x + 1] * 64, c0 = desc[3 * blockIdx.x + 2] * 64;
+  const float* __restrict__ src = reinterpret_cast<const float*>(src_ptrs[t]);
+  bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(dst_ptrs[t]);
+  const int R = dims[2 * t], C = dims[2 * t + 1];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty * 16 + i, c = c0 + tx;
+    tile[ty * 16 + i][tx] = (r < R && c < C) ? src[(int64_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty * 16 + i, r = r0 + tx;
+    if (c < C && r < R) dst[(int64_t)c * R + r] = (bf16_t)tile[tx][ty * 16 + i];
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p,
                                                       float inv_keep, uint64_t seed) {
@@ -375,6 +398,16 @@ extern "C" int fcmf_cast_transpose(const float* src, void* dst, int rows, int co
   if (rows == 0 || cols == 0) return FCMF_OK;
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (bf16_t*)dst, rows, cols);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_multi_cast_transpose(const int64_t* src_ptrs, const int64_t* dst_ptrs, const int32_t* dims,
+                                         const int32_t* tile_desc, int ntiles, void* stream) {
+  if (!src_ptrs || !dst_ptrs || !dims || !tile_desc || ntiles < 0) return FCMF_ERR_ARG;
+  if (ntiles == 0) return FCMF_OK;
+  hipLaunchKernelGGL(multi_cast_transpose_kernel, dim3(ntiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src_ptrs,
+                     dst_ptrs, dims, tile_desc);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }

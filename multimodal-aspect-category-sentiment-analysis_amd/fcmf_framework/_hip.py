@@ -59,6 +59,7 @@ SIGNATURES = {
     "fcmf_xent_bwd": [_vp, _i64, _vp, _vp, _i64, _vp, _f, _i, _i, _i64, _i, _vp],
     "fcmf_cast": [_vp, _vp, _i64, _i, _i, _vp],
     "fcmf_cast_transpose": [_vp, _vp, _i, _i, _vp],
+    "fcmf_multi_cast_transpose": [_vp, _vp, _vp, _vp, _i, _vp],
     "fcmf_dropout": [_vp, _vp, _i64, _f, _u64, _i, _vp],
     "fcmf_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "fcmf_sum_axis": [_vp, _vp, _i64, _i, _i64, _i, _vp],

@@ -60,6 +60,7 @@ class _Shadows:
         self.pad = {}
         self.mapT = {}
         self.mapD = {}
+        self._mt_tables = None
 
     def get_t(self, w):
         """bf16 TRANSPOSE [K, N] of a float32 [N, K] weight: dX = dY W then reads W^T as a K-contiguous operand
@@ -74,8 +75,34 @@ class _Shadows:
         if not src.is_contiguous():
             src = src.contiguous()
         H.check(H.lib().fcmf_cast_transpose(H.ptr(src), H.ptr(sh), w.shape[0], w.shape[1], H.stream()), "fcmf_cast_transpose")
-        self.mapT[key] = [sh, w._version, False]
+        self.mapT[key] = [sh, w._version, False, w.is_contiguous()]
         return sh
+
+    def refresh_transposed(self):
+        """rebuild EVERY cached transposed copy in one launch (called by the fused optimizers right after their update:
+        all of them are stale at that point, and rebuilding them lazily costs one small launch per weight)"""
+        if not self.mapT:
+            return
+        items = [(k, ent) for k, ent in self.mapT.items() if ent[3]]      # (sources read in place must be dense [R, C])
+        if not items:
+            return
+        sig = tuple((k[0], ent[0].data_ptr()) for k, ent in items)
+        if self._mt_tables is None or self._mt_tables[0] != sig:
+            dev = items[0][1][0].device
+            desc = []
+            for t, (k, ent) in enumerate(items):
+                R, C = k[1]
+                desc += [(t, r, c) for r in range((R + 63) // 64) for c in range((C + 63) // 64)]
+            self._mt_tables = (sig,
+                               torch.tensor([k[0] for k, _ in items], dtype=torch.int64, device=dev),
+                               torch.tensor([ent[0].data_ptr() for _, ent in items], dtype=torch.int64, device=dev),
+                               torch.tensor([list(k[1]) for k, _ in items], dtype=torch.int32, device=dev),
+                               torch.tensor(desc, dtype=torch.int32, device=dev), len(desc))
+        _, src, dst, dims, desc, n = self._mt_tables
+        H.check(H.lib().fcmf_multi_cast_transpose(H.ptr(src), H.ptr(dst), H.ptr(dims), H.ptr(desc), n, H.stream()),
+                "fcmf_multi_cast_transpose")
+        for _, ent in items:
+            ent[2] = False
 
     def padded(self, w):
         """the fresh bf16 copy of a 2-D weight including its zero rows up to a multiple of 32"""
@@ -140,6 +167,7 @@ class _Shadows:
         self.pad.clear()
         self.mapT.clear()
         self.mapD.clear()
+        self._mt_tables = None
 
 
 shadows = _Shadows()

@@ -220,6 +220,7 @@ class FusedAdamW(Optimizer):
                                    self.CHUNK, lr, wd, ng, b1, b2, eps, step, H.ptr(self._sumsq), mg, st),
                 "fcmf_multi_adamw")
         ops.shadows.mark_all_stale()          # e.g. fused [3H,H] q|k|v shadows are re-cast lazily
+        ops.shadows.refresh_transposed()      # ... the transposed copies (dX GEMM operands) all at once, one launch
         for (p, _), s in zip(plist, sh):
             self.state[p]['step'] = step
             if s is not None:

@@ -12,6 +12,11 @@ for p in (ROOT, PKG):
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+# CPU oracles run on this many threads: a one-GPU box of the pool owns 16 cores of a much larger host, and torch's default
+# (one thread per visible core) oversubscribes them ~10x (tests/oracle_thread_scan.py)
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -622,6 +622,29 @@ def test_fused_adamw_resumes_from_torch_adamw_checkpoint(dev):
         assert max_err(opt.state[p]["exp_avg"], ref.state[r]["exp_avg"]) < 1e-6
 
 
+def test_transposed_weight_copies_refreshed_in_one_launch(dev):
+    """the bf16 transposed copies the dX GEMMs read are rebuilt by ONE multi-tensor launch inside FusedAdamW.step: they
+    must equal the transpose of the UPDATED weights (ragged tile edges included) without any lazy per-weight rebuild"""
+    ops, H = _ops()
+    from fcmf_framework.optimization import FusedAdamW
+    ops.shadows.clear()
+    ws = [torch.nn.Parameter(_rand(s, dev, seed=i)) for i, s in enumerate([(768, 96), (100, 200), (64, 64)])]
+    bias = torch.nn.Parameter(_rand((96,), dev, seed=9))
+    for w in ws:
+        assert torch.equal(ops.shadows.get_t(w), w.detach().t().contiguous().bfloat16())
+    opt = FusedAdamW(ws + [bias], lr=1e-2)
+    for p in ws + [bias]:
+        p.grad = _rand(p.shape, dev, seed=20 + p.numel() % 7)
+    before = [w.detach().clone() for w in ws]
+    opt.step()
+    for w, b in zip(ws, before):
+        ent = ops.shadows.mapT[(w.data_ptr(), tuple(w.shape))]
+        assert ent[2] is False                                   # fresh: nothing left to rebuild lazily
+        assert not torch.equal(w.detach(), b)
+        assert torch.equal(ent[0], w.detach().t().contiguous().bfloat16())
+    ops.shadows.clear()
+
+
 def test_bertadam_matches_golden(dev):
     import os
     from conftest import GOLD

@@ -59,7 +59,7 @@ def test_oracle_base_logits():
     """FCMF-base geometry, forward only (the backward pin ran inside oracle/make_golden.py)"""
     cfg = synth.BASE_CFG
     z, P, batch, NI, NR = _fixture("base", cfg)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     with torch.no_grad():
         loss, logits = O.fcmf_step_loss(P, cfg, batch, NI, NR)
     assert (logits - torch.from_numpy(z["logits"])).abs().max() < 1e-5
