@@ -438,6 +438,11 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   struct Src { unsigned a[A_PIECES], b[B_PIECES]; };
   auto sources = [&](const Item& w) -> Src {
     Src r;
+#ifdef FCMF_GEMM_ABLATE_SRC
+    for (int j = 0; j < A_PIECES; ++j) r.a[j] = (unsigned)lane * 16u;
+    for (int j = 0; j < B_PIECES; ++j) r.b[j] = (unsigned)lane * 16u;
+    return r;
+#endif
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR>(a_piece0 + j, lane, p.lda, w.i0, p.M);
 #pragma unroll
@@ -450,7 +455,11 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     return;
 #endif
     char* st = stage_at(s);
+#ifdef FCMF_GEMM_ABLATE_SRC      // diagnostic build: every DMA piece re-reads the SAME first 1 KiB of its operand (L1 hits)
+    const unsigned ka = 0, kb = 0;
+#else
     const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
+#endif
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
       if (MI != 8 && j >= na_pieces) break;
@@ -487,11 +496,20 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   auto wait_landed = [&](int t, auto per_tile) {
     constexpr int PT = decltype(per_tile)::value;   // DMAs per k-tile of this wave: 4, or 3 for waves 4-7 of the 192-row tile
     const int younger = nkt - 1 - t;
+#ifdef FCMF_GEMM_DEPTH2        // diagnostic build: two k-tiles in flight instead of three (prefetch-depth sensitivity)
+    if (younger >= 1) { if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+#endif
     if (younger >= 2) { if (PT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else if (younger == 1) { if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto issue_after_barrier = [&](int t) {
+#ifdef FCMF_GEMM_DEPTH2
+    if (t + 2 < nkt) issue(w, src, t + 2, base + t + 2);
+    return;
+#endif
     if (t + 3 < nkt) issue(w, src, t + 3, base + t + 3);
   };
 
@@ -501,7 +519,14 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 #pragma unroll
     for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 fa[MI], fb[4];
+#ifdef FCMF_GEMM_ABLATE_FRAGS
+  for (int f = 0; f < MI; ++f) fa[f] = bf16x8{};
+  for (int f = 0; f < 4; ++f) fb[f] = bf16x8{};
+#endif
   auto load_frags = [&](int t) {
+#ifdef FCMF_GEMM_ABLATE_FRAGS    // diagnostic build (with ABLATE_MMA): no fragment reads either -> the DMA stream alone
+    return;
+#endif
     const char* st = stage_at(base + t);
 #pragma unroll
     for (int f = 0; f < 4; ++f) fb[f] = frag_b(st, f);
@@ -527,7 +552,9 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   if (!pre) {
     issue(w, src, 0, base);
     if (1 < nkt) issue(w, src, 1, base + 1);
+#ifndef FCMF_GEMM_DEPTH2
     if (2 < nkt) issue(w, src, 2, base + 2);
+#endif
   }
   // aux operand of the epilogue (gelu' argument / residual), row layout: 16 B per lane, 8 rows of the wave's
   // 128x64 sub-tile per instruction, 4 instructions per 32-row round.  Rounds 0 and 1 are requested before the
@@ -629,7 +656,9 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         const Src snx = sources(wnx);
         issue(wnx, snx, 0, nbase);
         if (1 < wnx.nkt) issue(wnx, snx, 1, nbase + 1);
+#ifndef FCMF_GEMM_DEPTH2
         if (2 < wnx.nkt) issue(wnx, snx, 2, nbase + 2);
+#endif
       }
     }
     FCMF_STAMP(3);
