@@ -206,8 +206,7 @@ def run_fcmf(args, rank, world, dev):
     sched = get_linear_schedule_with_warmup(opt, int(0.1 * 1000), 1000)
     red = arena = None
     if world > 1 or args.arena:
-        live = [p for n, p in model.named_parameters() if "bert.cell.pooler" not in n]     # the pooler never gets a gradient
-        arena = GradArena(live)
+        arena = GradArena.for_model(model)     # (leaves out bert.cell.pooler: it never gets a gradient)
         if world > 1:
             red = GradReducer(arena)
             red.broadcast_parameters(0)
@@ -289,9 +288,9 @@ def run_iaog(args, rank, world, dev):
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     opt = FusedAdamW([{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 1e-5},
                       {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}], lr=3e-5)
-    red = arena = None
+    arena = GradArena.for_model(model)      # one memset per step instead of a zero fill per weight gradient
+    red = None
     if world > 1:
-        arena = GradArena([p for n, p in named if "bert.cell.pooler" not in n])
         red = GradReducer(arena)
         red.broadcast_parameters(0)
     b = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, num_aspects=1, seed=3 + rank, coord_dtype=torch.float32)

@@ -270,15 +270,18 @@ int fcmf_conv_im2col(const void* src, int src_dtype, void* dst, int dst_dtype, i
 /* GROUPED BatchNorm2d batch statistics.  The reference calls the trunk once per image index / per (image, ROI)
  * with B crops each (run_multimodal_fcmf.py:449-457) in train() mode (:431): rows are packed group-major, group g
  * = rows [g*rows_per_group, (g+1)*rows_per_group), and every group gets ITS OWN statistics.
- * sums: double [groups, C, 2] (sum, sum of squares), overwritten. */
+ * sums: double workspace of fcmf_bn_stats_workspace(rows_per_group, groups, C) elements, fully overwritten with
+ * per-(group, row chunk, channel) partial (sum, sum of squares) pairs -- no atomics; fcmf_bn_finalize adds the chunks. */
+int64_t fcmf_bn_stats_workspace(int64_t rows_per_group, int groups, int C);
 int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group, int groups, int C, int dtype, void* stream);
-/* sums != NULL (training): scale/shift [groups, C] from each group's batch mean and biased variance
- * (y = x*scale + shift == (x-mean)/sqrt(var+eps)*gamma + beta); running_mean / running_var receive one
- * momentum update per group in group order with the unbiased variance (nn.BatchNorm2d over `groups` calls).
- * sums == NULL (eval): scale/shift [C] from the running statistics.  count = elements per (group, channel). */
+/* sums != NULL (training; as written by fcmf_bn_stats with rows_per_group == count): scale/shift [groups, C] from
+ * each group's batch mean and biased variance (y = x*scale + shift == (x-mean)/sqrt(var+eps)*gamma + beta);
+ * running_mean / running_var receive one momentum update per group in group order with the unbiased variance
+ * (nn.BatchNorm2d over `groups` calls).  sums == NULL (eval): scale/shift [C] from the running statistics.
+ * mean_out / rstd_out (both or neither; [groups, C], eval: [C]): the statistics the backward needs. */
 int fcmf_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
-                     float* running_var, float* scale, float* shift, int C, int groups, int64_t count,
-                     float momentum, float eps, void* stream);
+                     float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
+                     int groups, int64_t count, float momentum, float eps, void* stream);
 /* y = relu?(x * scale[g] + shift[g] (+ res)), g = row / rows_per_group (eval: rows_per_group = rows); y may alias x.
  * (bn -> relu, and the bottleneck's bn3 -> += identity -> relu) */
 int fcmf_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows,
@@ -290,6 +293,26 @@ int fcmf_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int dt
  * builds with view/permute, run_multimodal_fcmf.py:451).  oh = ow = 1 is myResNetRoI's x.mean(3).mean(2) (:48). */
 int fcmf_adaptive_avgpool(const void* x, float* y, int N, int H, int W, int C, int oh, int ow, int layout,
                           int dtype, void* stream);
+
+/* ---- backward of the trunk (fine-tuning the CNN: resnet_utils.py if_fine_tune=True, --fine_tune_cnn) ----
+ * BatchNorm2d (+ the ReLU behind it) backward, grouped like the forward.  g: gradient wrt the block output z; z: that
+ * output (ReLU mask z > 0; NULL = no ReLU); y: the convolution output the forward normalised; mean/rstd from
+ * fcmf_bn_finalize.  dy <- gradient wrt y: gamma*rstd*(gm - mean_rows(gm) - xhat*mean_rows(gm*xhat)) with gm = g*[z>0]
+ * (training != 0) or gamma*rstd*gm (eval); gres (may be NULL) <- gm, the gradient of the identity branch that was added
+ * before the ReLU; dgamma / dbeta float32 [C] are ACCUMULATED.  dy / gres may alias g.
+ * sums: double workspace of fcmf_bn_stats_workspace(...) + groups*C*2 elements. */
+int fcmf_bn_bwd(const void* g, const void* z, const void* y, const float* mean, const float* rstd, const float* gamma,
+                double* sums, void* dy, void* gres, float* dgamma, float* dbeta, int64_t rows_per_group, int groups,
+                int C, int training, int dtype, void* stream);
+/* transpose of fcmf_conv_im2col (NHWC, same dtype both sides): dX[n,h,w,c] = sum of dA over the windows covering the
+ * pixel, gathered per input pixel (no atomics).  dA [N*Ho*Wo, Kpad] = dY * W is the patch-matrix gradient. */
+int fcmf_conv_col2im(const void* dA, void* dX, int N, int H, int W, int C, int kh, int kw, int stride, int pad,
+                     int Kpad, int dtype, void* stream);
+/* nn.MaxPool2d(3, 2, 1) backward: dX gets dY of every window whose first maximum (scan order) the pixel is */
+int fcmf_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream);
+/* F.adaptive_avg_pool2d backward: dy float32 in the forward's output layout (0 = [N,C,oh,ow], 1 = [N,oh*ow,C]) */
+int fcmf_adaptive_avgpool_bwd(const float* dy, void* dx, int N, int H, int W, int C, int oh, int ow, int layout,
+                              int dtype, void* stream);
 
 #ifdef __cplusplus
 }

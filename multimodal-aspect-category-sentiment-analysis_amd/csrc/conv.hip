@@ -95,10 +95,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
       ds[0] += a.x; ds[1] += a.y; ds[2] += a.z; ds[3] += a.w;
       dq[0] += b.x; dq[1] += b.y; dq[2] += b.z; dq[3] += b.w;
     }
-    double* o = sums + ((int64_t)g * C + c0) * 2;
+    // partial of this (group, row chunk): plain stores (hundreds of workgroups adding into the same few cache lines
+    // with double atomics made this kernel 6x slower than its HBM traffic); the finalize kernels sum the chunks
+    double* o = sums + (((int64_t)g * gridDim.y + blockIdx.y) * C + c0) * 2;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { atomicAdd(o + 2 * e, ds[e]); atomicAdd(o + 2 * e + 1, dq[e]); }
+    for (int e = 0; e < 4; ++e) { o[2 * e] = ds[e]; o[2 * e + 1] = dq[e]; }
   }
+}
+
+// sum of the row-chunk partials of (group g, channel c): sums [G][nchunks][C][2]
+__device__ __forceinline__ void sum_chunks(const double* __restrict__ sums, int g, int c, int C, int nchunks, double& s, double& q) {
+  s = 0; q = 0;
+  const double* p = sums + ((int64_t)g * nchunks * C + c) * 2;
+  for (int k = 0; k < nchunks; ++k) { s += p[0]; q += p[1]; p += (int64_t)C * 2; }
 }
 
 // one thread per channel.  training: group g's batch mean / biased variance -> scale/shift[g]; running statistics
@@ -107,26 +116,30 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, float* __restrict__ scale,
-                                                          float* __restrict__ shift, int C, int G, double count,
-                                                          float momentum, float eps) {
+                                                          float* __restrict__ shift, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out, int C, int G, int nchunks,
+                                                          double count, float momentum, float eps) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const float w = gamma[c], b = beta[c];
   if (!sums) {
-    const float sc = w / sqrtf(rvar[c] + eps);
+    const float rs = 1.0f / sqrtf(rvar[c] + eps), sc = w * rs;
     scale[c] = sc;
     shift[c] = b - rmean[c] * sc;
+    if (mean_out) { mean_out[c] = rmean[c]; rstd_out[c] = rs; }
     return;
   }
   float rm = rmean[c], rv = rvar[c];
   for (int g = 0; g < G; ++g) {
-    const double s = sums[((int64_t)g * C + c) * 2], q = sums[((int64_t)g * C + c) * 2 + 1];
+    double s, q;
+    sum_chunks(sums, g, c, C, nchunks, s, q);
     const double mean = s / count;
     double var = q / count - mean * mean;
     var = var > 0 ? var : 0;
-    const float sc = w / sqrtf((float)var + eps);
+    const float rs = 1.0f / sqrtf((float)var + eps), sc = w * rs;
     scale[(int64_t)g * C + c] = sc;
     shift[(int64_t)g * C + c] = b - (float)mean * sc;
+    if (mean_out) { mean_out[(int64_t)g * C + c] = (float)mean; rstd_out[(int64_t)g * C + c] = rs; }
     const double unbiased = count > 1 ? var * count / (count - 1) : var;
     rm = (1.f - momentum) * rm + momentum * (float)mean;
     rv = (1.f - momentum) * rv + momentum * (float)unbiased;
@@ -206,6 +219,199 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, f
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// backward (fine-tuning the CNN, resnet_utils.py if_fine_tune=True / --fine_tune_cnn)
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm backward, pass 1: per (group, channel) s1 = sum gm, s2 = sum gm * xhat with gm = g * [z > 0] (the ReLU
+// that follows the normalisation; z == NULL: no ReLU) and xhat = (y - mean) * rstd.  Same decomposition as bn_stats.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ g, const T* __restrict__ z, const T* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           double* __restrict__ sums, int C, int64_t rows_per_group, int chunk) {
+  __shared__ float4 red[2][256];
+  const int slab_c = C < 256 ? C : 256, vpr = slab_c >> 2, rpp = 256 / vpr;
+  const int cv = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
+  const int c0 = blockIdx.x * 256 + cv * 4;
+  const int gi = blockIdx.z;
+  const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = min(rows_per_group, r0 + chunk);
+  float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+  if (c0 < C) {
+    const int64_t base = ((int64_t)gi * rows_per_group) * C + c0;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + (int64_t)gi * C + c0);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)gi * C + c0);
+    for (int64_t r = r0 + rsub; r < r1; r += rpp) {
+      float4 gv = Vec4<T>::load(g + base + r * C);
+      const float4 yv = Vec4<T>::load(y + base + r * C);
+      if (z) {
+        const float4 zv = Vec4<T>::load(z + base + r * C);
+        gv.x = zv.x > 0.f ? gv.x : 0.f; gv.y = zv.y > 0.f ? gv.y : 0.f; gv.z = zv.z > 0.f ? gv.z : 0.f; gv.w = zv.w > 0.f ? gv.w : 0.f;
+      }
+      s.x += gv.x; s.y += gv.y; s.z += gv.z; s.w += gv.w;
+      q.x += gv.x * (yv.x - mu.x) * rs.x; q.y += gv.y * (yv.y - mu.y) * rs.y;
+      q.z += gv.z * (yv.z - mu.z) * rs.z; q.w += gv.w * (yv.w - mu.w) * rs.w;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (rsub == 0 && c0 < C) {
+    double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+    for (int k = 0; k < rpp; ++k) {
+      const float4 a = red[0][k * vpr + cv], b = red[1][k * vpr + cv];
+      ds[0] += a.x; ds[1] += a.y; ds[2] += a.z; ds[3] += a.w;
+      dq[0] += b.x; dq[1] += b.y; dq[2] += b.z; dq[3] += b.w;
+    }
+    double* o = sums + (((int64_t)gi * gridDim.y + blockIdx.y) * C + c0) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = ds[e]; o[2 * e + 1] = dq[e]; }
+  }
+}
+
+// the chunk partials of the backward statistics -> totals [G][C][2] (+ dgamma / dbeta accumulated over the groups)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const double* __restrict__ sums, double* __restrict__ tot,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int G,
+                                                            int nchunks) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0, b = 0;
+  for (int g = 0; g < G; ++g) {
+    double s, q;
+    sum_chunks(sums, g, c, C, nchunks, s, q);
+    tot[((int64_t)g * C + c) * 2] = s;
+    tot[((int64_t)g * C + c) * 2 + 1] = q;
+    b += s; a += q;
+  }
+  dgamma[c] += (float)a;
+  dbeta[c] += (float)b;
+}
+
+// pass 2: dy = gamma * rstd * (gm - s1/n - xhat * s2/n) (training) or gamma * rstd * gm (eval: statistics are constants);
+// gres (optional) <- gm, the gradient that flows on into the identity branch of a bottleneck.  dy / gres may alias g.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* g, const T* __restrict__ z, const T* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                           T* dy, T* gres, int64_t rows, int C, int64_t rows_per_group) {
+  const int C4 = C >> 2;
+  const double inv_n = 1.0 / (double)rows_per_group;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < rows * C4; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / C4;
+    const int c = (int)(idx - row * C4) * 4;
+    const int64_t gi = row / rows_per_group;
+    float4 gv = Vec4<T>::load(g + row * C + c);
+    if (z) {
+      const float4 zv = Vec4<T>::load(z + row * C + c);
+      gv.x = zv.x > 0.f ? gv.x : 0.f; gv.y = zv.y > 0.f ? gv.y : 0.f; gv.z = zv.z > 0.f ? gv.z : 0.f; gv.w = zv.w > 0.f ? gv.w : 0.f;
+    }
+    if (gres) Vec4<T>::store(gres + row * C + c, gv);
+    const float4 yv = Vec4<T>::load(y + row * C + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + gi * C + c);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + gi * C + c);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+    float4 o;
+    if (sums) {
+      const double* sp = sums + (gi * C + c) * 2;
+      const float m1[4] = {(float)(sp[0] * inv_n), (float)(sp[2] * inv_n), (float)(sp[4] * inv_n), (float)(sp[6] * inv_n)};
+      const float m2[4] = {(float)(sp[1] * inv_n), (float)(sp[3] * inv_n), (float)(sp[5] * inv_n), (float)(sp[7] * inv_n)};
+      o.x = gm.x * rs.x * (gv.x - m1[0] - (yv.x - mu.x) * rs.x * m2[0]);
+      o.y = gm.y * rs.y * (gv.y - m1[1] - (yv.y - mu.y) * rs.y * m2[1]);
+      o.z = gm.z * rs.z * (gv.z - m1[2] - (yv.z - mu.z) * rs.z * m2[2]);
+      o.w = gm.w * rs.w * (gv.w - m1[3] - (yv.w - mu.w) * rs.w * m2[3]);
+    } else {
+      o.x = gm.x * rs.x * gv.x; o.y = gm.y * rs.y * gv.y; o.z = gm.z * rs.z * gv.z; o.w = gm.w * rs.w * gv.w;
+    }
+    Vec4<T>::store(dy + row * C + c, o);
+  }
+}
+
+// transpose of im2col without atomics: every INPUT pixel gathers the patch-matrix gradients of the windows that
+// cover it.  dA [N*Ho*Wo, Kpad] (k = (r, s, c)) -> dX [N, H, W, C]; 4 channels per thread, f32 accumulation.
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dA, T* __restrict__ dX, int N, int H, int W, int C,
+                                                     int kh, int kw, int stride, int pad, int Ho, int Wo, int Kpad) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)N * H * W * C4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C4) * 4;
+    const int64_t p = idx / C4;
+    const int wi = (int)(p % W), hi = (int)((p / W) % H);
+    const int64_t n = p / ((int64_t)W * H);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int r = 0; r < kh; ++r) {
+      const int th = hi + pad - r;
+      if (th < 0 || th % stride != 0) continue;
+      const int ho = th / stride;
+      if (ho >= Ho) continue;
+      for (int s2 = 0; s2 < kw; ++s2) {
+        const int tw = wi + pad - s2;
+        if (tw < 0 || tw % stride != 0) continue;
+        const int wo = tw / stride;
+        if (wo >= Wo) continue;
+        const float4 v = Vec4<T>::load(dA + ((n * Ho + ho) * Wo + wo) * Kpad + (r * kw + s2) * C + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    Vec4<T>::store(dX + p * C + c, acc);
+  }
+}
+
+// 3x3 / stride 2 / pad 1 max-pool backward, gather form: an input pixel receives dY of every window whose FIRST maximum
+// (scan order r, then s: torch's tie rule) it is.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dY, T* __restrict__ dX,
+                                                               int N, int H, int W, int C, int Ho, int Wo) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const int64_t p = idx / C;
+    const int wi = (int)(p % W), hi = (int)((p / W) % H);
+    const int64_t n = p / ((int64_t)W * H);
+    float acc = 0.f;
+    for (int ho = max(0, (hi - 1 + 1) / 2); ho <= min(Ho - 1, (hi + 1) / 2); ++ho)
+      for (int wo = max(0, (wi - 1 + 1) / 2); wo <= min(Wo - 1, (wi + 1) / 2); ++wo) {
+        // first maximum of window (ho, wo)
+        float best = -INFINITY; int bh = -1, bw = -1;
+        for (int r = 0; r < 3; ++r) {
+          const int h2 = ho * 2 + r - 1;
+          if (h2 < 0 || h2 >= H) continue;
+          for (int s2 = 0; s2 < 3; ++s2) {
+            const int w2 = wo * 2 + s2 - 1;
+            if (w2 < 0 || w2 >= W) continue;
+            const float v = to_f32<T>(x[((n * H + h2) * W + w2) * C + c]);
+            if (v > best || bh < 0) { best = v; bh = h2; bw = w2; }
+          }
+        }
+        if (bh == hi && bw == wi) acc += to_f32<T>(dY[((n * Ho + ho) * Wo + wo) * C + c]);
+      }
+    dX[idx] = from_f32<T>(acc);
+  }
+}
+
+// adaptive average pool backward: dY float32 in the forward's output layout -> dX [N,H,W,C]
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dY, T* __restrict__ dX, int N, int H, int W, int C,
+                                                          int oh, int ow, int layout) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const int64_t p = idx / C;
+    const int w = (int)(p % W), h = (int)((p / W) % H);
+    const int64_t n = p / ((int64_t)W * H);
+    float acc = 0.f;
+    for (int i = 0; i < oh; ++i) {
+      const int h0 = (i * H) / oh, h1 = ((i + 1) * H + oh - 1) / oh;
+      if (h < h0 || h >= h1) continue;
+      for (int j = 0; j < ow; ++j) {
+        const int w0 = (j * W) / ow, w1 = ((j + 1) * W + ow - 1) / ow;
+        if (w < w0 || w >= w1) continue;
+        const float d = layout == 0 ? dY[((n * C + c) * oh + i) * ow + j] : dY[((n * oh + i) * ow + j) * C + c];
+        acc += d / (float)((h1 - h0) * (w1 - w0));
+      }
+    }
+    dX[idx] = from_f32<T>(acc);
+  }
+}
+
 static inline int grid_for(int64_t work) {
   const int64_t b = (work + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -246,20 +452,32 @@ extern "C" int fcmf_conv_im2col(const void* src, int src_dtype, void* dst, int d
   return FCMF_OK;
 }
 
-extern "C" int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group, int groups, int C, int dtype,
-                             void* stream) {
-  if (!x || !sums || rows_per_group <= 0 || groups <= 0 || C <= 0 || C % 4 != 0 || (C < 256 && 256 % (C / 4) != 0) ||
-      (C > 256 && C % 256 != 0))
-    return FCMF_ERR_ARG;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)groups * C, st) != hipSuccess) return FCMF_ERR_LAUNCH;
-  // chunk: enough workgroups to fill the chip, at most 1024 rows per workgroup (short float partial sums)
+// row chunking of the statistics kernels: enough workgroups to fill the chip, at most 1024 rows per workgroup (short float
+// partial sums).  Returns the number of chunks per group (= partial rows per (group, channel) in `sums`).
+static int bn_chunking(int64_t rows_per_group, int groups, int C, int* chunk_rows) {
   const int slabs = (C + 255) / 256;
   int64_t chunks = (2048 + (int64_t)slabs * groups - 1) / ((int64_t)slabs * groups);
   int64_t chunk = (rows_per_group + chunks - 1) / chunks;
   if (chunk > 1024) chunk = 1024;
   if (chunk < 16) chunk = 16;
   chunks = (rows_per_group + chunk - 1) / chunk;
+  if (chunk_rows) *chunk_rows = (int)chunk;
+  return (int)chunks;
+}
+static bool bn_shape_ok(int C) { return C > 0 && C % 4 == 0 && (C >= 256 ? C % 256 == 0 : 256 % (C / 4) == 0); }
+
+extern "C" int64_t fcmf_bn_stats_workspace(int64_t rows_per_group, int groups, int C) {
+  if (rows_per_group <= 0 || groups <= 0 || !bn_shape_ok(C)) return 0;
+  return (int64_t)groups * bn_chunking(rows_per_group, groups, C, nullptr) * C * 2;      // doubles
+}
+
+extern "C" int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group, int groups, int C, int dtype,
+                             void* stream) {
+  if (!x || !sums || rows_per_group <= 0 || groups <= 0 || !bn_shape_ok(C)) return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int slabs = (C + 255) / 256;
+  int chunk;
+  const int chunks = bn_chunking(rows_per_group, groups, C, &chunk);
   if (chunks > 65535 || groups > 65535) return FCMF_ERR_UNSUPPORTED;
   dim3 grid(slabs, (unsigned)chunks, groups);
   if (dtype == FCMF_F32) hipLaunchKernelGGL((bn_stats_kernel<float>), grid, dim3(256), 0, st, (const float*)x, sums, C, rows_per_group, (int)chunk);
@@ -270,12 +488,14 @@ extern "C" int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group
 }
 
 extern "C" int fcmf_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
-                                float* running_var, float* scale, float* shift, int C, int groups, int64_t count,
-                                float momentum, float eps, void* stream) {
+                                float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
+                                int groups, int64_t count, float momentum, float eps, void* stream) {
   if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0 || groups <= 0) return FCMF_ERR_ARG;
-  if (sums && count <= 0) return FCMF_ERR_ARG;
+  if ((sums && count <= 0) || ((mean_out == nullptr) != (rstd_out == nullptr))) return FCMF_ERR_ARG;
+  const int nchunks = sums ? bn_chunking(count, groups, C, nullptr) : 0;      // the layout fcmf_bn_stats wrote
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
-                     gamma, beta, running_mean, running_var, scale, shift, C, groups, (double)count, momentum, eps);
+                     gamma, beta, running_mean, running_var, scale, shift, mean_out, rstd_out, C, groups, nchunks, (double)count,
+                     momentum, eps);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
@@ -312,6 +532,76 @@ extern "C" int fcmf_adaptive_avgpool(const void* x, float* y, int N, int H, int 
   const int g = grid_for((int64_t)N * oh * ow * C);
   if (dtype == FCMF_F32) hipLaunchKernelGGL((avgpool_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, y, N, H, W, C, oh, ow, layout);
   else if (dtype == FCMF_BF16) hipLaunchKernelGGL((avgpool_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, y, N, H, W, C, oh, ow, layout);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_bn_bwd(const void* g, const void* z, const void* y, const float* mean, const float* rstd, const float* gamma,
+                           double* sums, void* dy, void* gres, float* dgamma, float* dbeta, int64_t rows_per_group, int groups,
+                           int C, int training, int dtype, void* stream) {
+  if (!g || !y || !mean || !rstd || !gamma || !dy || !dgamma || !dbeta || !sums || rows_per_group <= 0 || groups <= 0 ||
+      !bn_shape_ok(C))
+    return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int slabs = (C + 255) / 256;
+  int chunk;
+  const int chunks = bn_chunking(rows_per_group, groups, C, &chunk);
+  if (chunks > 65535 || groups > 65535) return FCMF_ERR_UNSUPPORTED;
+  dim3 grid(slabs, (unsigned)chunks, groups);
+  double* tot = sums + (int64_t)groups * chunks * C * 2;       // totals [G][C][2] behind the chunk partials
+  const int64_t rows = rows_per_group * groups;
+  const int ga = grid_for(rows * (C / 4));
+#define FCMF_BNB(T)                                                                                                              \
+  do {                                                                                                                          \
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T>), grid, dim3(256), 0, st, (const T*)g, (const T*)z, (const T*)y, mean, rstd, sums, C, \
+                       rows_per_group, chunk);                                                                                  \
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, tot, dgamma, dbeta, C, groups, chunks); \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ga), dim3(256), 0, st, (const T*)g, (const T*)z, (const T*)y, mean, rstd,  \
+                       gamma, training ? (const double*)tot : (const double*)nullptr, (T*)dy, (T*)gres, rows, C, rows_per_group); \
+  } while (0)
+  if (dtype == FCMF_F32) FCMF_BNB(float);
+  else if (dtype == FCMF_BF16) FCMF_BNB(bf16_t);
+  else return FCMF_ERR_UNSUPPORTED;
+#undef FCMF_BNB
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_conv_col2im(const void* dA, void* dX, int N, int H, int W, int C, int kh, int kw, int stride, int pad,
+                                int Kpad, int dtype, void* stream) {
+  if (!dA || !dX || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 ||
+      Kpad < kh * kw * C)
+    return FCMF_ERR_ARG;
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for((int64_t)N * H * W * (C / 4));
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((col2im_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dA, (float*)dX, N, H, W, C, kh, kw, stride, pad, Ho, Wo, Kpad);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((col2im_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)dA, (bf16_t*)dX, N, H, W, C, kh, kw, stride, pad, Ho, Wo, Kpad);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream) {
+  if (!x || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FCMF_ERR_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for((int64_t)N * H * W * C);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_adaptive_avgpool_bwd(const float* dy, void* dx, int N, int H, int W, int C, int oh, int ow, int layout,
+                                         int dtype, void* stream) {
+  if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || oh <= 0 || ow <= 0 || (layout != 0 && layout != 1)) return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for((int64_t)N * H * W * C);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((avgpool_bwd_kernel<float>), dim3(g), dim3(256), 0, st, dy, (float*)dx, N, H, W, C, oh, ow, layout);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((avgpool_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, dy, (bf16_t*)dx, N, H, W, C, oh, ow, layout);
   else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;

@@ -69,7 +69,12 @@ SIGNATURES = {
     "fcmf_bertadam": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp],
     "fcmf_conv_im2col": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _vp],
     "fcmf_bn_stats": [_vp, _vp, _i64, _i, _i, _i, _vp],
-    "fcmf_bn_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _f, _f, _vp],
+    "fcmf_bn_stats_workspace": [_i64, _i, _i],
+    "fcmf_bn_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _f, _f, _vp],
+    "fcmf_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
+    "fcmf_conv_col2im": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_maxpool3x3s2_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "fcmf_adaptive_avgpool_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_bn_apply": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _vp],
     "fcmf_maxpool3x3s2": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "fcmf_adaptive_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -97,7 +102,7 @@ def lib():
             fn.argtypes = args
             fn.restype = (ctypes.c_char_p if name in ("fcmf_build_info", "fcmf_gemm_last_kernel") else
                           None if name == "fcmf_gemm_force_tile" else
-                          ctypes.c_int64 if name == "fcmf_add_ln_bwd_workspace" else ctypes.c_int)
+                          ctypes.c_int64 if name in ("fcmf_add_ln_bwd_workspace", "fcmf_bn_stats_workspace") else ctypes.c_int)
         _lib = l
     return _lib
 

@@ -321,6 +321,19 @@ def gemm_dx(dy, weight, w_compute, dx, M, K_in, N_out, aux=None, epi=H.EPI_NONE,
         gemm(dy, w_compute, dx, M, K_in, N_out, N_out, K_in, K_in, 0, 1, aux=aux, epi=epi, colsum=colsum)
 
 
+def gemm_dx_long_k(dy, w, M, K_in, N_out, ldw):
+    """dx [M,K_in] = dy [M,N_out] @ w [N_out,K_in] for a LONG contraction and a small output (the vocabulary projection:
+    N_out = 64032, M x K_in = 768 x 768): a bf16 output has 9 tiles of 256x256 = 9 busy CUs; accumulating into float32 lets
+    the kernel split the contraction 28 ways over the chip (workspace + reduce pass), then one cast"""
+    if dy.dtype != torch.bfloat16 or N_out < 8192:
+        dx = torch.empty((M, K_in), dtype=dy.dtype, device=dy.device)
+        gemm(dy, w, dx, M, K_in, N_out, N_out, ldw, K_in, 0, 1)
+        return dx
+    dx32 = torch.zeros((M, K_in), dtype=torch.float32, device=dy.device)
+    gemm(dy, w, dx32, M, K_in, N_out, N_out, ldw, K_in, 0, 1, acc=True)
+    return cast(dx32, torch.bfloat16)
+
+
 def _linear_fwd(x, w, bias, epi=H.EPI_NONE, aux=None):
     M, K = x.shape
     N = w.shape[0]
@@ -466,9 +479,7 @@ class VocabLinearFn(torch.autograd.Function):
         dyp[:, :V] = dy.reshape(M, V)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
-            gemm(dyp, wp, dx, M, K, Vp, Vp, K, K, 0, 1)
-            dx = dx.view(ctx.xshape)
+            dx = gemm_dx_long_k(dyp, wp, M, K, Vp, K).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros((Vp, K), dtype=torch.float32, device=x2.device)
             gemm(dyp, x2, dwp, Vp, K, M, Vp, _ld(x2), K, 1, 1, acc=True)
@@ -534,9 +545,7 @@ class VocabCrossEntropyFn(torch.autograd.Function):
             d[:, V:].zero_()                                # the padding logits (= bias 0) must not leak into dX / dW
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
-            gemm(d, w, dx, M, K, Vp, Vp, K, K, 0, 1)
-            dx = dx.view(xshape)
+            dx = gemm_dx_long_k(d, w, M, K, Vp, K).view(xshape)
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros((Vp, K), dtype=torch.float32, device=x2.device)
             gemm(d, x2, dwp, Vp, K, M, Vp, _ld(x2), K, 1, 1, acc=True)

@@ -12,9 +12,11 @@ wrappers do.  Underneath:
     each, in train() mode (run_multimodal_fcmf.py:431,449-457), so batch statistics belong to each B-crop call.
     `trunk(x, groups=G)` runs all G calls as one batch with per-group statistics and G running-statistics updates in
     call order -- bit-for-bit the reference's semantics without its Python loop of num_imgs * num_rois launches;
-  * forward only: with if_fine_tune=False (the default of both drivers) the reference detaches the features
-    (resnet_utils.py:26-28); --fine_tune_cnn needs convolution / BatchNorm backward kernels that do not exist yet,
-    and asking for it raises instead of silently running something else.
+  * with if_fine_tune=False (the default of both drivers) the reference detaches the features
+    (resnet_utils.py:26-28) and the trunk runs forward only; with if_fine_tune=True (--fine_tune_cnn) `TrunkFn` records
+    what the backward needs (inputs, raw convolution outputs, normalised outputs, batch statistics) and walks the
+    network in reverse by hand: BatchNorm(+ReLU) backward kernels, dX = dY W / dW = dY^T A on the GEMM kernels (the
+    patch matrix is rebuilt, not stored), col2im, max-pool and average-pool backward.
 There is no torch (MIOpen) fallback: CPU tensors raise HipLibraryError.
 """
 import torch
@@ -84,21 +86,25 @@ def conv2d_nhwc(x, conv, src_strides=None):
     return y.view(N, Ho, Wo, Cout)
 
 
-def batchnorm_nhwc_(y, bn, groups=1, res=None, relu=False):
-    """in-place BatchNorm2d (+ residual, + ReLU) of y [N,H,W,C]; training mode: per-group batch statistics and
-    `groups` running-statistics updates (module docstring)"""
+def batchnorm_nhwc_(y, bn, groups=1, res=None, relu=False, out=None, save=None):
+    """BatchNorm2d (+ residual, + ReLU) of y [N,H,W,C], in place (or into `out`); training mode: per-group batch
+    statistics and `groups` running-statistics updates (module docstring).  save: dict that receives mean / rstd /
+    groups / training for the backward."""
     N, Hh, Ww, C = y.shape
     rows = N * Hh * Ww
     L, st = H.lib(), H.stream()
     dev = y.device
     training = bn.training or not bn.track_running_stats
+    mean = rstd = None
     if training:
         if N % groups != 0:
             raise H.HipLibraryError(f"grouped BatchNorm: {N} crops do not split into {groups} equal groups")
         rpg = rows // groups
-        sums = torch.empty((groups, C, 2), dtype=torch.float64, device=dev)
+        sums = torch.empty(L.fcmf_bn_stats_workspace(rpg, groups, C), dtype=torch.float64, device=dev)
         scale = torch.empty((groups, C), dtype=torch.float32, device=dev)
         shift = torch.empty((groups, C), dtype=torch.float32, device=dev)
+        if save is not None:
+            mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
         H.check(L.fcmf_bn_stats(H.ptr(y), H.ptr(sums), rpg, groups, C, H.dt(y), st), "fcmf_bn_stats")
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
         if bn.track_running_stats:
@@ -106,18 +112,34 @@ def batchnorm_nhwc_(y, bn, groups=1, res=None, relu=False):
         else:
             rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
         H.check(L.fcmf_bn_finalize(H.ptr(sums), H.ptr(bn.weight), H.ptr(bn.bias), H.ptr(rm), H.ptr(rv), H.ptr(scale),
-                                   H.ptr(shift), C, groups, rpg, mom, float(bn.eps), st), "fcmf_bn_finalize")
+                                   H.ptr(shift), H.ptr(mean), H.ptr(rstd), C, groups, rpg, mom, float(bn.eps), st),
+                "fcmf_bn_finalize")
         if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += groups
+            bn._pending_batches = getattr(bn, "_pending_batches", 0) + groups      # flushed lazily (one add, not 155 per pass)
     else:
-        rpg = rows
+        rpg, groups = rows, 1
         scale = torch.empty(C, dtype=torch.float32, device=dev)
         shift = torch.empty(C, dtype=torch.float32, device=dev)
+        if save is not None:
+            mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
         H.check(L.fcmf_bn_finalize(0, H.ptr(bn.weight), H.ptr(bn.bias), H.ptr(bn.running_mean), H.ptr(bn.running_var),
-                                   H.ptr(scale), H.ptr(shift), C, 1, 0, 0.0, float(bn.eps), st), "fcmf_bn_finalize")
-    H.check(L.fcmf_bn_apply(H.ptr(y), H.ptr(res), H.ptr(y), H.ptr(scale), H.ptr(shift), rows, C, rpg, int(relu), H.dt(y),
+                                   H.ptr(scale), H.ptr(shift), H.ptr(mean), H.ptr(rstd), C, 1, 0, 0.0, float(bn.eps), st),
+                "fcmf_bn_finalize")
+    z = y if out is None else out
+    H.check(L.fcmf_bn_apply(H.ptr(y), H.ptr(res), H.ptr(z), H.ptr(scale), H.ptr(shift), rows, C, rpg, int(relu), H.dt(y),
                             st), "fcmf_bn_apply")
-    return y
+    if save is not None:
+        save.update(mean=mean, rstd=rstd, groups=groups, training=training, rpg=rpg)
+    return z
+
+
+def flush_batch_counters(module):
+    """apply the pending `num_batches_tracked` increments of every BatchNorm2d under `module`"""
+    for m in module.modules():
+        n = getattr(m, "_pending_batches", 0)
+        if n and isinstance(m, BatchNorm2d):
+            m.num_batches_tracked += n
+            m._pending_batches = 0
 
 
 def maxpool3x3s2_nhwc(x):
@@ -138,6 +160,112 @@ def adaptive_avgpool_nhwc(x, oh, ow, tokens=False):
 
 
 # ---------------------------------------------------------------------------------------
+# backward building blocks (fine-tuning the CNN)
+# ---------------------------------------------------------------------------------------
+def _grad_of(grads, p):
+    g = grads.get(p)
+    if g is None:
+        g = grads[p] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+    return g
+
+
+def conv2d_bwd_nhwc(conv, x, dy, grads, need_dx=True, src_strides=None, add=None):
+    """dy [N,Ho,Wo,Cout] -> dx [N,H,W,C] (+ `add`, the gradient arriving on a parallel branch); the weight gradient
+    dW = dY^T A is accumulated into grads[conv.weight].  The patch matrix A is rebuilt from x, not stored."""
+    dt = dy.dtype
+    N, Hh, Ww, C = x.shape
+    kh, kw = conv.kernel_size
+    st, pad = conv.stride[0], conv.padding[0]
+    Cout = conv.out_channels
+    wm, Kpad = _weight_matrix(conv, dt)
+    K = kh * kw * C
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    rows = N * Ho * Wo
+    dy2 = dy.reshape(rows, Cout)
+    direct = kh == 1 and kw == 1 and st == 1 and pad == 0 and src_strides is None and x.dtype == dt and x.is_contiguous()
+    L, stream = H.lib(), H.stream()
+    if direct:
+        A = x.view(rows, C)
+    else:
+        A = torch.empty((rows, Kpad), dtype=dt, device=dy.device)
+        sn, sh, sw, sc = src_strides if src_strides is not None else x.stride()
+        H.check(L.fcmf_conv_im2col(H.ptr(x), H.dt(x), H.ptr(A), H.dt(A), N, Hh, Ww, C, sn, sh, sw, sc, kh, kw, st, pad, Kpad,
+                                   stream), "fcmf_conv_im2col")
+    dwm = torch.zeros((Cout, Kpad), dtype=torch.float32, device=dy.device)
+    ops.gemm(dy2, A, dwm, Cout, Kpad, rows, Cout, Kpad, Kpad, 1, 1, acc=True)
+    _grad_of(grads, conv.weight).add_(dwm[:, :K].reshape(Cout, kh, kw, C).permute(0, 3, 1, 2))
+    if not need_dx:
+        return None
+    if direct:
+        dx = torch.empty((rows, C), dtype=dt, device=dy.device)
+        if add is not None:
+            ops.gemm(dy2, wm, dx, rows, Kpad, Cout, Cout, Kpad, Kpad, 0, 1, aux=add.reshape(rows, C), epi=H.EPI_ADD)
+        else:
+            ops.gemm(dy2, wm, dx, rows, Kpad, Cout, Cout, Kpad, Kpad, 0, 1)
+        return dx.view(N, Hh, Ww, C)
+    dA = torch.empty((rows, Kpad), dtype=dt, device=dy.device)
+    ops.gemm(dy2, wm, dA, rows, Kpad, Cout, Cout, Kpad, Kpad, 0, 1)
+    dx = torch.empty((N, Hh, Ww, C), dtype=dt, device=dy.device)
+    H.check(L.fcmf_conv_col2im(H.ptr(dA), H.ptr(dx), N, Hh, Ww, C, kh, kw, st, pad, Kpad, H.dt(dx), stream), "fcmf_conv_col2im")
+    if add is not None:
+        raise H.HipLibraryError("conv2d_bwd_nhwc: `add` is only fused into 1x1 / stride-1 convolutions")
+    return dx
+
+
+def batchnorm_bwd_nhwc_(bn, rec, g, y, z, grads, want_gres=False):
+    """g (gradient wrt the normalised, optionally ReLU'd output z) -> gradient wrt the convolution output y, IN PLACE in
+    g; returns (dy, gres) with gres = the ReLU-masked g for the identity branch (a new tensor) when want_gres"""
+    N, Hh, Ww, C = y.shape
+    L = H.lib()
+    groups, rpg = rec["groups"], rec["rpg"]
+    ws = torch.empty(L.fcmf_bn_stats_workspace(rpg, groups, C) + groups * C * 2, dtype=torch.float64, device=y.device)
+    gres = torch.empty_like(g) if want_gres else None
+    H.check(L.fcmf_bn_bwd(H.ptr(g), H.ptr(z), H.ptr(y), H.ptr(rec["mean"]), H.ptr(rec["rstd"]), H.ptr(bn.weight), H.ptr(ws),
+                          H.ptr(g), H.ptr(gres), H.ptr(_grad_of(grads, bn.weight)), H.ptr(_grad_of(grads, bn.bias)), rpg, groups, C,
+                          int(rec["training"]), H.dt(g), H.stream()), "fcmf_bn_bwd")
+    return g, gres
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """adaptive average pool of an NHWC activation with its backward kernel"""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow, tokens):
+        ctx.cfg = (x.shape, x.dtype, oh, ow, tokens)
+        return adaptive_avgpool_nhwc(x, oh, ow, tokens)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (N, Hh, Ww, C), dt, oh, ow, tokens = ctx.cfg
+        dx = torch.empty((N, Hh, Ww, C), dtype=dt, device=dy.device)
+        d = dy.contiguous().float()
+        H.check(H.lib().fcmf_adaptive_avgpool_bwd(H.ptr(d), H.ptr(dx), N, Hh, Ww, C, oh, ow, int(tokens), H.dt(dx), H.stream()),
+                "fcmf_adaptive_avgpool_bwd")
+        return dx, None, None, None
+
+
+class TrunkFn(torch.autograd.Function):
+    """conv1 -> bn1 -> relu -> maxpool -> layer1..4 of ONE pass (<= MAX_CROPS_PER_PASS crops) with a hand-written
+    backward.  Inputs: the crops, the network, the group count, then every trunk parameter (so that autograd routes the
+    gradients); output: the NHWC activation [N, h, w, 2048]."""
+
+    @staticmethod
+    def forward(ctx, x, net, groups, *params):
+        tape = []
+        y = net._trunk_pass(x, groups, tape)
+        ctx.net, ctx.tape, ctx.nparams = net, tape, len(params)
+        ctx.params = params
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = {}
+        ctx.net._trunk_backward(ctx.tape, g.contiguous(), grads)
+        ctx.tape = None
+        return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+# ---------------------------------------------------------------------------------------
 # module tree (torchvision names); every forward takes / returns NCHW-shaped tensors
 # ---------------------------------------------------------------------------------------
 class Conv2d(nn.Conv2d):
@@ -155,10 +283,25 @@ class Conv2d(nn.Conv2d):
 class BatchNorm2d(nn.BatchNorm2d):
     groups = 1     # number of reference calls packed into the batch (set by ResNet.trunk)
 
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._pending_batches = 0
+        self._register_state_dict_hook(BatchNorm2d._flush_hook)
+
+    @staticmethod
+    def _flush_hook(module, state_dict, prefix, local_metadata):
+        n = module._pending_batches
+        if n and module.num_batches_tracked is not None:
+            module.num_batches_tracked += n
+            module._pending_batches = 0
+            state_dict[prefix + "num_batches_tracked"] = module.num_batches_tracked
+
     def forward(self, x):
         v = _nhwc(x)
         v = v.clone() if v.data_ptr() == x.data_ptr() else v        # module API: do not overwrite the caller's tensor
-        return _nchw(batchnorm_nhwc_(v, self, self.groups))
+        out = _nchw(batchnorm_nhwc_(v, self, self.groups))
+        flush_batch_counters(self)
+        return out
 
 
 class ReLU(nn.Module):
@@ -216,6 +359,38 @@ class Bottleneck(nn.Module):
             x = batchnorm_nhwc_(conv2d_nhwc(x, self.downsample[0]), self.downsample[1], groups)
         return batchnorm_nhwc_(out, self.bn3, groups, res=x, relu=True)       # bn3 -> += identity -> relu, one pass
 
+    def forward_rec(self, x, groups, tape):
+        """forward_nhwc that keeps what the backward needs (raw convolution outputs are NOT overwritten)"""
+        r = {"x": x, "blk": self}
+        for i, (conv, bn, src) in enumerate(((self.conv1, self.bn1, "x"), (self.conv2, self.bn2, "z1"), (self.conv3, self.bn3, "z2")), 1):
+            y = conv2d_nhwc(r[src], conv)
+            r[f"y{i}"], r[f"s{i}"] = y, {}
+            if i < 3:
+                r[f"z{i}"] = batchnorm_nhwc_(y, bn, groups, relu=True, out=torch.empty_like(y), save=r[f"s{i}"])
+        idn = x
+        if self.downsample is not None:
+            r["yd"], r["sd"] = conv2d_nhwc(x, self.downsample[0]), {}
+            idn = batchnorm_nhwc_(r["yd"], self.downsample[1], groups, out=torch.empty_like(r["yd"]), save=r["sd"])
+        r["z3"] = batchnorm_nhwc_(r["y3"], self.bn3, groups, res=idn, relu=True, out=torch.empty_like(r["y3"]), save=r["s3"])
+        tape.append(r)
+        return r["z3"]
+
+    def backward_rec(self, r, g, grads):
+        """g: gradient wrt the block output -> gradient wrt the block input (parameter gradients into `grads`)"""
+        dy3, gres = batchnorm_bwd_nhwc_(self.bn3, r["s3"], g, r["y3"], r["z3"], grads, want_gres=True)
+        dz2 = conv2d_bwd_nhwc(self.conv3, r["z2"], dy3, grads)
+        dy2, _ = batchnorm_bwd_nhwc_(self.bn2, r["s2"], dz2, r["y2"], r["z2"], grads)
+        dz1 = conv2d_bwd_nhwc(self.conv2, r["z1"], dy2, grads)
+        dy1, _ = batchnorm_bwd_nhwc_(self.bn1, r["s1"], dz1, r["y1"], r["z1"], grads)
+        if self.downsample is not None:
+            dyd, _ = batchnorm_bwd_nhwc_(self.downsample[1], r["sd"], gres, r["yd"], None, grads)
+            conv_d = self.downsample[0]
+            if conv_d.stride[0] == 1:        # layer1.0: both branches are 1x1 / stride 1 -> the second GEMM adds the first
+                dxd = conv2d_bwd_nhwc(conv_d, r["x"], dyd, grads)
+                return conv2d_bwd_nhwc(self.conv1, r["x"], dy1, grads, add=dxd)
+            gres = conv2d_bwd_nhwc(conv_d, r["x"], dyd, grads)      # strided: col2im output, added by conv1's GEMM below
+        return conv2d_bwd_nhwc(self.conv1, r["x"], dy1, grads, add=gres)
+
     def forward(self, x):
         return _nchw(self.forward_nhwc(_nhwc(x), self.bn1.groups))
 
@@ -252,10 +427,15 @@ class ResNet(nn.Module):
             if isinstance(m, BatchNorm2d):
                 m.groups = groups
 
-    @torch.no_grad()
-    def trunk_nhwc(self, x, groups=1):
-        """x [N,3,H,W] (any float dtype / layout), N = groups * B crops packed group-major -> NHWC [N,h,w,C]"""
+    def trunk_params(self):
+        return [p for n, p in self.named_parameters() if not n.startswith("fc.")]
+
+    def trunk_nhwc(self, x, groups=1, fine_tune=False):
+        """x [N,3,H,W] (any float dtype / layout), N = groups * B crops packed group-major -> NHWC [N,h,w,C].
+        fine_tune=False: forward only, detached (the reference's `Variable(x.data)`, resnet_utils.py:26-28);
+        fine_tune=True under grad mode: differentiable wrt the trunk parameters (TrunkFn)."""
         H.require_cuda(x)
+        grad = fine_tune and torch.is_grad_enabled() and any(p.requires_grad for p in self.trunk_params())
         if x.shape[0] % groups != 0:
             raise H.HipLibraryError(f"{x.shape[0]} crops do not split into {groups} equal groups")
         per = x.shape[0] // groups
@@ -265,19 +445,45 @@ class ResNet(nn.Module):
         outs = []
         for g0 in range(0, groups, gpp):
             g1 = min(groups, g0 + gpp)
-            outs.append(self._trunk_pass(x[g0 * per:g1 * per], g1 - g0))
+            xs = x[g0 * per:g1 * per]
+            if grad:
+                outs.append(TrunkFn.apply(xs, self, g1 - g0, *self.trunk_params()))
+            else:
+                with torch.no_grad():
+                    outs.append(self._trunk_pass(xs, g1 - g0))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
-    def _trunk_pass(self, x, groups):
+    def _trunk_pass(self, x, groups, tape=None):
+        """tape is None: activations are normalised in place, nothing is kept; else: recording forward for TrunkFn"""
         xs = x if x.dtype in (torch.float32, torch.bfloat16) else x.float()
         v = xs.permute(0, 2, 3, 1)                                       # strided NHWC view of the NCHW crops
         y = conv2d_nhwc(v, self.conv1, src_strides=v.stride())
-        y = batchnorm_nhwc_(y, self.bn1, groups, relu=True)
-        y = maxpool3x3s2_nhwc(y)
+        if tape is None:
+            y = batchnorm_nhwc_(y, self.bn1, groups, relu=True)
+            y = maxpool3x3s2_nhwc(y)
+            for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in layer:
+                    y = blk.forward_nhwc(y, groups)
+            return y
+        stem = {"v": v, "y": y, "s": {}}
+        stem["z"] = batchnorm_nhwc_(y, self.bn1, groups, relu=True, out=torch.empty_like(y), save=stem["s"])
+        tape.append(stem)
+        y = maxpool3x3s2_nhwc(stem["z"])
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
-                y = blk.forward_nhwc(y, groups)
+                y = blk.forward_rec(y, groups, tape)
         return y
+
+    def _trunk_backward(self, tape, g, grads):
+        for r in reversed(tape[1:]):
+            g = r["blk"].backward_rec(r, g, grads)
+        stem = tape[0]
+        z = stem["z"]
+        N, Hh, Ww, C = z.shape
+        dz = torch.empty_like(z)
+        H.check(H.lib().fcmf_maxpool3x3s2_bwd(H.ptr(z), H.ptr(g), H.ptr(dz), N, Hh, Ww, C, H.dt(z), H.stream()), "fcmf_maxpool3x3s2_bwd")
+        dy, _ = batchnorm_bwd_nhwc_(self.bn1, stem["s"], dz, stem["y"], z, grads)
+        conv2d_bwd_nhwc(self.conv1, stem["v"], dy, grads, need_dx=False, src_strides=stem["v"].stride())
 
     def forward(self, x):
         """torchvision's ResNet.forward (classification head); not on the FCMF path, kept for API parity"""

@@ -14,7 +14,6 @@ import torch
 import torch.nn as nn
 
 from . import resnet as R
-from ._hip import HipLibraryError
 
 
 class myResNetImg(nn.Module):
@@ -24,16 +23,15 @@ class myResNetImg(nn.Module):
         self.if_fine_tune = if_fine_tune
         self.device = device
 
-    def _check(self):
-        if self.if_fine_tune and torch.is_grad_enabled() and any(p.requires_grad for p in self.resnet.parameters()):
-            raise HipLibraryError("fine-tuning the CNN (--fine_tune_cnn / if_fine_tune=True) needs convolution and "
-                                  "BatchNorm backward kernels, which are not built; run with if_fine_tune=False "
-                                  "(both drivers' default) or under torch.no_grad()")
+    def _pool(self, feat, oh, ow, tokens=False):
+        if feat.requires_grad:                         # if_fine_tune=True under grad mode: differentiable pooling
+            return R.AvgPoolFn.apply(feat, oh, ow, tokens)
+        return R.adaptive_avgpool_nhwc(feat, oh, ow, tokens=tokens)
 
     def forward_groups(self, x, groups=1, att_size=7, tokens=False):
-        """x [groups*B, 3, H, W] packed group-major -> [groups*B, 2048, att, att] (tokens: [groups*B, att*att, 2048])"""
-        self._check()
-        return R.adaptive_avgpool_nhwc(self.resnet.trunk_nhwc(x, groups), att_size, att_size, tokens=tokens)
+        """x [groups*B, 3, H, W] packed group-major -> [groups*B, 2048, att, att] (tokens: [groups*B, att*att, 2048]);
+        detached unless if_fine_tune (resnet_utils.py:26-28)"""
+        return self._pool(self.resnet.trunk_nhwc(x, groups, fine_tune=bool(self.if_fine_tune)), att_size, att_size, tokens)
 
     def forward(self, x, att_size=7):
         return self.forward_groups(x, 1, att_size)       # detached by construction (resnet_utils.py:26-28)
@@ -42,8 +40,7 @@ class myResNetImg(nn.Module):
 class myResNetRoI(myResNetImg):
     def forward_groups(self, x, groups=1):
         """-> [groups*B, 2048]: x.mean(3).mean(2) of the trunk output (resnet_utils.py:48)"""
-        self._check()
-        return R.adaptive_avgpool_nhwc(self.resnet.trunk_nhwc(x, groups), 1, 1).flatten(1)
+        return self._pool(self.resnet.trunk_nhwc(x, groups, fine_tune=bool(self.if_fine_tune)), 1, 1).flatten(1)
 
     def forward(self, x):
         return self.forward_groups(x, 1)
