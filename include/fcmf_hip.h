@@ -271,7 +271,8 @@ int fcmf_conv_im2col(const void* src, int src_dtype, void* dst, int dst_dtype, i
  * with B crops each (run_multimodal_fcmf.py:449-457) in train() mode (:431): rows are packed group-major, group g
  * = rows [g*rows_per_group, (g+1)*rows_per_group), and every group gets ITS OWN statistics.
  * sums: double workspace of fcmf_bn_stats_workspace(rows_per_group, groups, C) elements, fully overwritten with
- * per-(group, row chunk, channel) partial (sum, sum of squares) pairs -- no atomics; fcmf_bn_finalize adds the chunks. */
+ * per-(group, row chunk, channel) partial (sum, sum of squares) pairs -- no atomics -- followed by their per-(group,
+ * channel) totals (a second, tree-reduction kernel); fcmf_bn_finalize reads the totals. */
 int64_t fcmf_bn_stats_workspace(int64_t rows_per_group, int groups, int C);
 int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group, int groups, int C, int dtype, void* stream);
 /* sums != NULL (training; as written by fcmf_bn_stats with rows_per_group == count): scale/shift [groups, C] from
@@ -300,7 +301,7 @@ int fcmf_adaptive_avgpool(const void* x, float* y, int N, int H, int W, int C, i
  * fcmf_bn_finalize.  dy <- gradient wrt y: gamma*rstd*(gm - mean_rows(gm) - xhat*mean_rows(gm*xhat)) with gm = g*[z>0]
  * (training != 0) or gamma*rstd*gm (eval); gres (may be NULL) <- gm, the gradient of the identity branch that was added
  * before the ReLU; dgamma / dbeta float32 [C] are ACCUMULATED.  dy / gres may alias g.
- * sums: double workspace of fcmf_bn_stats_workspace(...) + groups*C*2 elements. */
+ * sums: double workspace of fcmf_bn_stats_workspace(rows_per_group, groups, C) elements. */
 int fcmf_bn_bwd(const void* g, const void* z, const void* y, const float* mean, const float* rstd, const float* gamma,
                 double* sums, void* dy, void* gres, float* dgamma, float* dbeta, int64_t rows_per_group, int groups,
                 int C, int training, int dtype, void* stream);

@@ -103,11 +103,26 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   }
 }
 
-// sum of the row-chunk partials of (group g, channel c): sums [G][nchunks][C][2]
-__device__ __forceinline__ void sum_chunks(const double* __restrict__ sums, int g, int c, int C, int nchunks, double& s, double& q) {
-  s = 0; q = 0;
-  const double* p = sums + ((int64_t)g * nchunks * C + c) * 2;
-  for (int k = 0; k < nchunks; ++k) { s += p[0]; q += p[1]; p += (int64_t)C * 2; }
+// the row-chunk partials of fcmf_bn_stats / the backward statistics -> totals tot[G][C][2].  grid (C/64, G), 16 waves:
+// lane = channel of a 64-channel slab, the waves stride the chunks (16-byte coalesced loads), LDS tree over the waves.
+__global__ __launch_bounds__(1024) void bn_reduce_chunks_kernel(const double* __restrict__ sums, double* __restrict__ tot, int C,
+                                                                int nchunks) {
+  __shared__ double red[2][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, g = blockIdx.y;
+  double s = 0, q = 0;
+  if (c < C) {
+    const double* p = sums + (((int64_t)g * nchunks + w) * C + c) * 2;
+    for (int k = w; k < nchunks; k += 16) { s += p[0]; q += p[1]; p += (int64_t)16 * C * 2; }
+  }
+  red[0][w][lane] = s;
+  red[1][w][lane] = q;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    for (int k = 1; k < 16; ++k) { s += red[0][k][lane]; q += red[1][k][lane]; }
+    tot[((int64_t)g * C + c) * 2] = s;
+    tot[((int64_t)g * C + c) * 2 + 1] = q;
+  }
 }
 
 // one thread per channel.  training: group g's batch mean / biased variance -> scale/shift[g]; running statistics
@@ -117,8 +132,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ mean_out,
-                                                          float* __restrict__ rstd_out, int C, int G, int nchunks,
-                                                          double count, float momentum, float eps) {
+                                                          float* __restrict__ rstd_out, int C, int G, double count,
+                                                          float momentum, float eps) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const float w = gamma[c], b = beta[c];
@@ -131,8 +146,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
   float rm = rmean[c], rv = rvar[c];
   for (int g = 0; g < G; ++g) {
-    double s, q;
-    sum_chunks(sums, g, c, C, nchunks, s, q);
+    const double s = sums[((int64_t)g * C + c) * 2], q = sums[((int64_t)g * C + c) * 2 + 1];      // totals
     const double mean = s / count;
     double var = q / count - mean * mean;
     var = var > 0 ? var : 0;
@@ -267,20 +281,13 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
   }
 }
 
-// the chunk partials of the backward statistics -> totals [G][C][2] (+ dgamma / dbeta accumulated over the groups)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const double* __restrict__ sums, double* __restrict__ tot,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int G,
-                                                            int nchunks) {
+// dgamma[c] += sum_g s2[g,c], dbeta[c] += sum_g s1[g,c] from the totals
+__global__ __launch_bounds__(256) void bn_bwd_params_kernel(const double* __restrict__ tot, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int C, int G) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double a = 0, b = 0;
-  for (int g = 0; g < G; ++g) {
-    double s, q;
-    sum_chunks(sums, g, c, C, nchunks, s, q);
-    tot[((int64_t)g * C + c) * 2] = s;
-    tot[((int64_t)g * C + c) * 2 + 1] = q;
-    b += s; a += q;
-  }
+  for (int g = 0; g < G; ++g) { b += tot[((int64_t)g * C + c) * 2]; a += tot[((int64_t)g * C + c) * 2 + 1]; }
   dgamma[c] += (float)a;
   dbeta[c] += (float)b;
 }
@@ -452,13 +459,13 @@ extern "C" int fcmf_conv_im2col(const void* src, int src_dtype, void* dst, int d
   return FCMF_OK;
 }
 
-// row chunking of the statistics kernels: enough workgroups to fill the chip, at most 1024 rows per workgroup (short float
-// partial sums).  Returns the number of chunks per group (= partial rows per (group, channel) in `sums`).
+// row chunking of the statistics kernels: enough workgroups to fill the chip, at most 4096 rows per workgroup (a thread's
+// float partial sum covers <= 1024 values; everything above is added in double).  Returns the number of chunks per group (= partial rows per (group, channel) in `sums`).
 static int bn_chunking(int64_t rows_per_group, int groups, int C, int* chunk_rows) {
   const int slabs = (C + 255) / 256;
-  int64_t chunks = (2048 + (int64_t)slabs * groups - 1) / ((int64_t)slabs * groups);
+  int64_t chunks = (1024 + (int64_t)slabs * groups - 1) / ((int64_t)slabs * groups);
   int64_t chunk = (rows_per_group + chunks - 1) / chunks;
-  if (chunk > 1024) chunk = 1024;
+  if (chunk > 4096) chunk = 4096;
   if (chunk < 16) chunk = 16;
   chunks = (rows_per_group + chunk - 1) / chunk;
   if (chunk_rows) *chunk_rows = (int)chunk;
@@ -468,7 +475,11 @@ static bool bn_shape_ok(int C) { return C > 0 && C % 4 == 0 && (C >= 256 ? C % 2
 
 extern "C" int64_t fcmf_bn_stats_workspace(int64_t rows_per_group, int groups, int C) {
   if (rows_per_group <= 0 || groups <= 0 || !bn_shape_ok(C)) return 0;
-  return (int64_t)groups * bn_chunking(rows_per_group, groups, C, nullptr) * C * 2;      // doubles
+  return ((int64_t)groups * bn_chunking(rows_per_group, groups, C, nullptr) + groups) * C * 2;      // doubles: partials + totals
+}
+// where the totals [G][C][2] live inside the workspace
+static double* bn_totals(double* sums, int64_t rows_per_group, int groups, int C) {
+  return sums + (int64_t)groups * bn_chunking(rows_per_group, groups, C, nullptr) * C * 2;
 }
 
 extern "C" int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group, int groups, int C, int dtype,
@@ -483,6 +494,8 @@ extern "C" int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group
   if (dtype == FCMF_F32) hipLaunchKernelGGL((bn_stats_kernel<float>), grid, dim3(256), 0, st, (const float*)x, sums, C, rows_per_group, (int)chunk);
   else if (dtype == FCMF_BF16) hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, sums, C, rows_per_group, (int)chunk);
   else return FCMF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_reduce_chunks_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, sums,
+                     bn_totals(sums, rows_per_group, groups, C), C, chunks);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
@@ -492,9 +505,9 @@ extern "C" int fcmf_bn_finalize(const double* sums, const float* gamma, const fl
                                 int groups, int64_t count, float momentum, float eps, void* stream) {
   if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0 || groups <= 0) return FCMF_ERR_ARG;
   if ((sums && count <= 0) || ((mean_out == nullptr) != (rstd_out == nullptr))) return FCMF_ERR_ARG;
-  const int nchunks = sums ? bn_chunking(count, groups, C, nullptr) : 0;      // the layout fcmf_bn_stats wrote
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
-                     gamma, beta, running_mean, running_var, scale, shift, mean_out, rstd_out, C, groups, nchunks, (double)count,
+  const double* tot = sums ? bn_totals(const_cast<double*>(sums), count, groups, C) : nullptr;   // where fcmf_bn_stats left them
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tot,
+                     gamma, beta, running_mean, running_var, scale, shift, mean_out, rstd_out, C, groups, (double)count,
                      momentum, eps);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
@@ -549,14 +562,15 @@ extern "C" int fcmf_bn_bwd(const void* g, const void* z, const void* y, const fl
   const int chunks = bn_chunking(rows_per_group, groups, C, &chunk);
   if (chunks > 65535 || groups > 65535) return FCMF_ERR_UNSUPPORTED;
   dim3 grid(slabs, (unsigned)chunks, groups);
-  double* tot = sums + (int64_t)groups * chunks * C * 2;       // totals [G][C][2] behind the chunk partials
+  double* tot = bn_totals(sums, rows_per_group, groups, C);     // totals [G][C][2] behind the chunk partials
   const int64_t rows = rows_per_group * groups;
   const int ga = grid_for(rows * (C / 4));
 #define FCMF_BNB(T)                                                                                                              \
   do {                                                                                                                          \
     hipLaunchKernelGGL((bn_bwd_stats_kernel<T>), grid, dim3(256), 0, st, (const T*)g, (const T*)z, (const T*)y, mean, rstd, sums, C, \
                        rows_per_group, chunk);                                                                                  \
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, tot, dgamma, dbeta, C, groups, chunks); \
+    hipLaunchKernelGGL(bn_reduce_chunks_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, sums, tot, C, chunks);         \
+    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, tot, dgamma, dbeta, C, groups);          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ga), dim3(256), 0, st, (const T*)g, (const T*)z, (const T*)y, mean, rstd,  \
                        gamma, training ? (const double*)tot : (const double*)nullptr, (T*)dy, (T*)gres, rows, C, rows_per_group); \
   } while (0)

@@ -1191,7 +1191,11 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     int ksplit = 1;
     // split K only where the output grid cannot fill the chip and C is an f32 accumulator
     // (weight gradients: K = number of tokens).
-    if (accumulate && epilogue == FCMF_EPI_NONE && tiles < 512) {
+    // The k-split partials of this kernel are added with float atomics in the fragment layout: a flat ~40 us per
+    // launch (memory-side read-modify-writes), so splitting pays only when the unsplit k-loop is longer than that
+    // (~0.45 us per k-tile: from ~96 k-tiles up).  Short contractions (the IAOG decoder's 768 x 768 x 768-row weight
+    // gradients: 110 launches per step at 48 us each when split) run one block per tile with a plain read-add-write.
+    if (accumulate && epilogue == FCMF_EPI_NONE && tiles < 512 && nk >= 96) {
       ksplit = 512 / tiles;   // one round of <= 512 resident blocks (256 CUs x 2)
       if (ksplit > nk / 4) ksplit = nk / 4 > 0 ? nk / 4 : 1;
       if (ksplit > 32) ksplit = 32;

@@ -218,7 +218,7 @@ def batchnorm_bwd_nhwc_(bn, rec, g, y, z, grads, want_gres=False):
     N, Hh, Ww, C = y.shape
     L = H.lib()
     groups, rpg = rec["groups"], rec["rpg"]
-    ws = torch.empty(L.fcmf_bn_stats_workspace(rpg, groups, C) + groups * C * 2, dtype=torch.float64, device=y.device)
+    ws = torch.empty(L.fcmf_bn_stats_workspace(rpg, groups, C), dtype=torch.float64, device=y.device)
     gres = torch.empty_like(g) if want_gres else None
     H.check(L.fcmf_bn_bwd(H.ptr(g), H.ptr(z), H.ptr(y), H.ptr(rec["mean"]), H.ptr(rec["rstd"]), H.ptr(bn.weight), H.ptr(ws),
                           H.ptr(g), H.ptr(gres), H.ptr(_grad_of(grads, bn.weight)), H.ptr(_grad_of(grads, bn.bias)), rpg, groups, C,
