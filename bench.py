@@ -16,6 +16,7 @@ Other workloads print their OWN line (never mixed into the headline metric):
   --workload iaog    IAOG seq2seq pre-training step (BASELINE configs[3] geometry per GPU: B=64, seq 128, Ld=12,
                      vocab 64001, 4 ROIs as run_pretraining_fcmf.py defaults), fused vocabulary projection + loss
   --workload resnet  the ResNet-152 feature extractor of the step: crops/s of the batched trunk
+  --workload fcmf-large  BASELINE configs[4] geometry (XLM-R-large, seq 256, 100 ROIs) in bf16 (its fp8 path is not built)
 
 One JSON line on stdout (rank 0).  `roofline` describes the dominant kernel (the bf16 MFMA GEMM family):
 achieved = executed GEMM FLOPs / summed launch durations measured with HIP events on the launch stream during the
@@ -186,7 +187,12 @@ def timed_loop(step, args, world, dev, trace=True):
 
 
 # ---------------------------------------------------------------------------------------
-def run_fcmf(args, rank, world, dev):
+LARGE_CFG = dict(vocab_size=250002, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                 intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1,
+                 layer_norm_eps=1e-5, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+
+
+def run_fcmf(args, rank, world, dev, large=False):
     import synthetic_data as synth
     from fcmf_framework import ops
     from fcmf_framework.dp import GradArena, GradReducer
@@ -194,10 +200,11 @@ def run_fcmf(args, rank, world, dev):
     from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup
     from fcmf_framework.roberta import RobertaConfig, RobertaModel
 
-    S, NI, NR, A, B = 128, 7, 36, 6, args.batch
+    CFG = LARGE_CFG if large else BASE_CFG
+    S, NI, NR, A, B = (256, 7, 100, 6, args.batch) if large else (128, 7, 36, 6, args.batch)
     torch.manual_seed(42)
     hf = tempfile.mkdtemp(prefix="hf_")
-    RobertaModel(RobertaConfig(**BASE_CFG)).save_pretrained(hf)
+    RobertaModel(RobertaConfig(**CFG)).save_pretrained(hf)
     model = FCMF(hf, num_labels=4, num_imgs=NI, num_roi=NR).to(dev)
     model.train(not args.no_dropout)
     ops.manual_seed(42 + rank)
@@ -210,7 +217,7 @@ def run_fcmf(args, rank, world, dev):
         if world > 1:
             red = GradReducer(arena)
             red.broadcast_parameters(0)
-    host = synth.synth_batch(B, BASE_CFG, S=S, num_imgs=NI, num_roi=NR, num_aspects=A, seed=42 + rank)
+    host = synth.synth_batch(B, CFG, S=S, num_imgs=NI, num_roi=NR, num_aspects=A, seed=42 + rank)
     batch = {k: v.to(dev) for k, v in host.items()}
 
     def step():
@@ -244,16 +251,20 @@ def run_fcmf(args, rank, world, dev):
     del tmp
     ms_step = dt / args.steps * 1e3
     out = {
-        "metric": "train samples/sec (fwd+bwd+step) FCMF seq128x36ROI",
+        "metric": "train samples/sec (fwd+bwd+step) FCMF-large seq256x100ROI (bf16; the fp8 path of BASELINE configs[4] is not built)"
+        if large else "train samples/sec (fwd+bwd+step) FCMF seq128x36ROI",
         "value": round(world * B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (seeded batch, random-init weights)",
-        "config": {"workload": "FCMF-base fine-tune step, BASELINE configs[1]: batch 64 reviews x 6 aspects per GPU, "
-                               "seq 128, 7 images x (49 patches + 36 ROIs), precomputed ResNet-152 features, dropout "
+        "config": {"workload": (f"FCMF-large (XLM-R-large geometry H1024 L24 heads16 I4096 vocab 250002) fine-tune step, BASELINE configs[4] "
+                                f"geometry in bf16: batch {B} reviews x 6 aspects per GPU, seq 256, 7 images x (49 patches + 100 ROIs), "
+                                "precomputed features, dropout " if large else
+                                "FCMF-base fine-tune step, BASELINE configs[1]: batch 64 reviews x 6 aspects per GPU, "
+                                "seq 128, 7 images x (49 patches + 36 ROIs), precomputed ResNet-152 features, dropout ")
                                + ("off" if args.no_dropout else "0.1") + ", clip 1.0 + 4-group AdamW + linear schedule",
                    "global_batch": world * B, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
                    "sample_unit": "1 review = 6 aspect forwards",
-                   "dense_flops_per_sample_fwd_bwd": algorithmic_flops_per_sample(BASE_CFG, S, NI, 49, NR, A)},
+                   "dense_flops_per_sample_fwd_bwd": algorithmic_flops_per_sample(CFG, S, NI, 49, NR, A)},
         "loss": round(float(loss.item()), 4),
         "h2d_ms_per_batch": round(h2d_ms, 2),
         "value_with_h2d": round(world * B / ((ms_step + h2d_ms) * 1e-3), 2),
@@ -261,7 +272,7 @@ def run_fcmf(args, rank, world, dev):
     }
     if comm is not None:
         out["dp"] = comm
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not large:
         out["cpu_baseline"] = cpu_baseline()
     return out
 
@@ -367,8 +378,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fcmf", choices=["fcmf", "iaog", "resnet"])
-    ap.add_argument("--batch", type=int, default=64, help="reviews per GPU")
+    ap.add_argument("--workload", default="fcmf", choices=["fcmf", "fcmf-large", "iaog", "resnet"])
+    ap.add_argument("--batch", type=int, default=None, help="reviews per GPU (default 64; fcmf-large: 16)")
     ap.add_argument("--dec_len", type=int, default=12, help="IAOG decoder length")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -394,7 +405,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
         else:
             dist.init_process_group(args.backend)
-    out = {"fcmf": run_fcmf, "iaog": run_iaog, "resnet": run_resnet}[args.workload](args, rank, world, dev)
+    if args.batch is None:
+        args.batch = 16 if args.workload == "fcmf-large" else 64
+    runner = {"fcmf": run_fcmf, "fcmf-large": lambda *a: run_fcmf(*a, large=True), "iaog": run_iaog, "resnet": run_resnet}
+    out = runner[args.workload](args, rank, world, dev)
     if rank == 0:
         if world > 1:
             out["dp_backend"] = dist.get_backend()

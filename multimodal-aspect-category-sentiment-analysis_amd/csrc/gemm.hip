@@ -1134,7 +1134,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     // (weight gradients: the 256x256 kernel's row-wise f32 epilogue / 256-byte atomics beat the 128x128 kernel's
     // fragment-layout atomics from K = 1024 up -- 25 vs 97 us at 768x768x2048)
     bool large = tile_ok && M >= 256 && N >= 256 &&
-                 ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && K >= 1024));
+                 ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && K >= 512));
     if (g_force_tile == 128) large = false;
     if (g_force_tile == 256 || g_force_tile == 192) large = tile_ok;
     if (large) {
@@ -1154,7 +1154,8 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       int ksplit = 1;
       if (accumulate && epilogue == FCMF_EPI_NONE && tiles_l < slots) {
         ksplit = slots / tiles_l;
-        if (ksplit > nk / 8) ksplit = nk / 8 > 0 ? nk / 8 : 1;
+        const int min_kt = nk >= 64 ? 8 : 6;      // k-tiles per work item: short contractions (K = 768 rows) split 4 ways
+        if (ksplit > nk / min_kt) ksplit = nk / min_kt > 0 ? nk / min_kt : 1;
         if (ksplit > 64) ksplit = 64;
       }
       p.ktiles_per_split = (nk + ksplit - 1) / ksplit;
@@ -1191,11 +1192,9 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     int ksplit = 1;
     // split K only where the output grid cannot fill the chip and C is an f32 accumulator
     // (weight gradients: K = number of tokens).
-    // The k-split partials of this kernel are added with float atomics in the fragment layout: a flat ~40 us per
-    // launch (memory-side read-modify-writes), so splitting pays only when the unsplit k-loop is longer than that
-    // (~0.45 us per k-tile: from ~96 k-tiles up).  Short contractions (the IAOG decoder's 768 x 768 x 768-row weight
-    // gradients: 110 launches per step at 48 us each when split) run one block per tile with a plain read-add-write.
-    if (accumulate && epilogue == FCMF_EPI_NONE && tiles < 512 && nk >= 96) {
+    // (unsplit, 36 lone workgroups of 24 k-tiles were measured SLOWER than 6-way split + float atomics on the IAOG
+    // decoder's 768 x 768 x 768-row weight gradients: a single workgroup per CU has nothing to overlap its latencies with)
+    if (accumulate && epilogue == FCMF_EPI_NONE && tiles < 512) {
       ksplit = 512 / tiles;   // one round of <= 512 resident blocks (256 CUs x 2)
       if (ksplit > nk / 4) ksplit = nk / 4 > 0 ? nk / 4 : 1;
       if (ksplit > 32) ksplit = 32;
