@@ -122,7 +122,8 @@ int fcmf_attn_small_bwd(const fcmf_attn_desc* desc /*host*/, const void* out, co
                         float* dbias, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * MFMA self/cross attention for bf16, head dim 64, Tk <= 128 (the text-encoder layers):
+ * MFMA self/cross attention for bf16, head dim 64, Tq, Tk <= 256 (the text-encoder layers: 128 tokens in FCMF-base,
+ * 256 in FCMF-large; the backward handles every query of a (sequence, head) in one workgroup, so Tq <= 256 there too):
  *   Q [G,Tq,heads*64], K/V [G,Tk,heads*64] (row strides ldq/ldk elements), mask [G,Tk] additive.
  * Replaces HF RobertaSelfAttention + eager_attention_forward and mm_modeling.py:193-219. */
 int fcmf_attn_mfma_fwd(const void* q, const void* k, const void* v, const float* mask,

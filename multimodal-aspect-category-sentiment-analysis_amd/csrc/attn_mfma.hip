@@ -1,4 +1,5 @@
-// MFMA attention for the text-encoder layers: bf16, head dim 64, Tk <= 128 keys per (sequence, head).
+// MFMA attention for the text-encoder layers: bf16, head dim 64, up to 256 queries / keys per (sequence, head)
+// (128: FCMF-base; 256: FCMF-large, in the <2,2> / 256-key instantiations further down).
 //   forward : one workgroup per (sequence, head, 128-query tile); K and V tiles staged once in LDS;
 //             each of the 4 waves owns 32 query rows: S^T = K Q^T on v_mfma_f32_16x16x32_bf16 with the
 //             key index in the accumulator registers (row max / sum = 32 in-lane values + 2 shuffles);
@@ -130,15 +131,22 @@ struct AttnMfmaParams {
 };
 
 // =========================================================================================
-__global__ __launch_bounds__(256, 3) void attn_mfma_fwd_kernel(AttnMfmaParams P) {
+// NKT = 128-key tiles per (sequence, head): 1 (Tk <= 128: 32 KiB of LDS, three workgroups per CU) or 2 (Tk <= 256: the
+// FCMF-large text encoder, 64 KiB, two per CU).  The images of the second tile lie right behind the first (row r of the
+// 256-row image = row r - 128 of the second tile: the swizzle keys only use row bits 1..3).
+template <int NKT>
+__device__ __forceinline__ void attn_mfma_fwd_body(const AttnMfmaParams& P) {
+  constexpr int NKF = 8 * NKT;       // 16-key fragments
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  char* Vs = smem + TILE_B;
+  char* Vs = smem + NKT * TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
   const int q0 = blockIdx.y * AT + w * 32;
-  const TileRegs kt = load_tile(P.k + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
-  const TileRegs vt = load_tile(P.v + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
+  const bf16_t* kbase_p = P.k + (int64_t)g * P.Tk * P.ldk + h * AD;
+  const bf16_t* vbase_p = P.v + (int64_t)g * P.Tk * P.ldk + h * AD;
+  const TileRegs kt = load_tile(kbase_p, P.ldk, P.Tk, tid);
+  const TileRegs vt = load_tile(vbase_p, P.ldk, P.Tk, tid);
 
   // Q fragments straight from global memory in operand layout (16 B per lane)
   bf16x8 qf[2][2];
@@ -153,18 +161,24 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_fwd_kernel(AttnMfmaParams P)
     }
   store_tile<false>(Ks, kt, tid);      // (all of K, V and Q were requested before the first LDS write)
   store_tile<true>(Vs, vt, tid);
+  if constexpr (NKT == 2) {
+    const TileRegs kt2 = load_tile(kbase_p + (int64_t)AT * P.ldk, P.ldk, P.Tk - AT, tid);
+    const TileRegs vt2 = load_tile(vbase_p + (int64_t)AT * P.ldk, P.ldk, P.Tk - AT, tid);
+    store_tile<false>(Ks + TILE_B, kt2, tid);
+    store_tile<true>(Vs + TILE_B, vt2, tid);
+  }
   __syncthreads();
 
-  // S^T[key][q]: 8 key fragments x 2 query fragments
-  f32x4 sc[8][2];
+  // S^T[key][q]: NKF key fragments x 2 query fragments
+  f32x4 sc[NKF][2];
 #pragma unroll
-  for (int kf = 0; kf < 8; ++kf)
+  for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
     for (int f = 0; f < 2; ++f) sc[kf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int kf = 0; kf < 8; ++kf) {
+    for (int kf = 0; kf < NKF; ++kf) {
       const bf16x8 ka = frag_row64(Ks, 16 * kf, s, lane);
 #pragma unroll
       for (int f = 0; f < 2; ++f) sc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[f][s], sc[kf][f], 0, 0, 0);
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_fwd_kernel(AttnMfmaParams P)
     const int q = q0 + 16 * f + (lane & 15);
     float m = -INFINITY;
 #pragma unroll
-    for (int kf = 0; kf < 8; ++kf)
+    for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * kf + 4 * (lane >> 4) + r;
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_fwd_kernel(AttnMfmaParams P)
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int kf = 0; kf < 8; ++kf)
+    for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __expf(sc[kf][f][r] - m);
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_fwd_kernel(AttnMfmaParams P)
     const float inv = 1.0f / sum;
     if (q < P.Tq && (lane >> 4) == 0 && P.lse) P.lse[((int64_t)g * P.heads + h) * P.Tq + q] = m + __logf(sum);
 #pragma unroll
-    for (int kf = 0; kf < 8; ++kf) {
+    for (int kf = 0; kf < NKF; ++kf) {
       float dm[4] = {1.f, 1.f, 1.f, 1.f};
       if (P.p > 0.f) dropout_mult4(P.seed, (((uint64_t)g * P.heads + h) * P.Tq + q) * P.Tk + 16 * kf + 4 * (lane >> 4), P.p, inv_keep, dm);
 #pragma unroll
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_fwd_kernel(AttnMfmaParams P)
 #pragma unroll
     for (int f = 0; f < 2; ++f) oc[df][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < 4 * NKT; ++s) {
     // P^T operand of k-step s straight from the accumulators of key fragments 2s and 2s+1
     bf16x8 pb[2];
 #pragma unroll
@@ -241,177 +255,213 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_fwd_kernel(AttnMfmaParams P)
   }
 }
 
+__global__ __launch_bounds__(256, 3) void attn_mfma_fwd_kernel(AttnMfmaParams P) { attn_mfma_fwd_body<1>(P); }
+__global__ __launch_bounds__(256, 2) void attn_mfma_fwd256_kernel(AttnMfmaParams P) { attn_mfma_fwd_body<2>(P); }
+
 // =========================================================================================
-__global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(AttnMfmaParams P) {
+// backward.  NQT = 128-query tiles, NKT = 128-key tiles handled by ONE workgroup per (sequence, head):
+//   <1,1>  Tq, Tk <= 128 : 80 KiB of LDS, two workgroups per CU (the FCMF-base text encoder);
+//   <2,2>  Tq, Tk <= 256 : 144 KiB, one workgroup per CU = one wave per SIMD with the whole register file (the
+//          FCMF-large text encoder, S = 256): the fragments of BOTH query tiles stay in registers, the key chunks go by
+//          once, and for every chunk the two query tiles take turns in the two chunk images, so that dK / dV of the chunk
+//          accumulate over all 256 queries in registers and are stored once -- no partial buffers, no atomics.
+template <int NQT, int NKT>
+__device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qs = smem;
-  char* Ks = smem + TILE_B;
-  char* Vs = smem + 2 * TILE_B;
-  char* dOs = smem + 3 * TILE_B;
-  char* PdT = smem + 4 * TILE_B;              // [32 keys][128 q] bf16 of the current key chunk, 8 KiB
-  char* dST = PdT + TILE_B / 2;               // 8 KiB
+  char* Qs = smem;                               // NQT tiles
+  char* dOs = Qs + NQT * TILE_B;                 // NQT tiles
+  char* Ks = dOs + NQT * TILE_B;                 // NKT tiles
+  char* Vs = Ks + NKT * TILE_B;                  // NKT tiles
+  char* PdT = Vs + NKT * TILE_B;                 // [32 keys][128 q] bf16 of the current (key chunk, query tile), 8 KiB
+  char* dST = PdT + TILE_B / 2;                  // 8 KiB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
   const int64_t qbase = (int64_t)g * P.Tq, kbase = (int64_t)g * P.Tk;
-  const TileRegs tq = load_tile(P.q + qbase * P.ldq + h * AD, P.ldq, P.Tq, tid);
-  const TileRegs tk = load_tile(P.k + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
-  const TileRegs tv = load_tile(P.v + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
-  const TileRegs td = load_tile(P.dout + qbase * P.ldo + h * AD, P.ldo, P.Tq, tid);
-  // delta[q] = sum_d dO[q][d] O[q][d] for the wave's 32 query rows: two lanes per row, then every lane picks
-  // the values of the rows its accumulator registers hold (no LDS: the 80 KiB are spoken for)
-  float dl4[2][4], lse4[2][4];
+  // delta[q] = sum_d dO[q][d] O[q][d] for the wave's 32 query rows of every query tile: two lanes per row, then every
+  // lane picks the values of the rows its accumulator registers hold
+  float dl4[NQT][2][4], lse4[NQT][2][4];
   {
-    const int q = 32 * w + (lane >> 1), half = lane & 1;
-    float sd = 0.f;
-    if (q < P.Tq) {
-      const bf16_t* a = P.dout + (qbase + q) * P.ldo + h * AD + 32 * half;
-      const bf16_t* b = P.o + (qbase + q) * P.ldo + h * AD + 32 * half;
+    TileRegs tq[NQT], td[NQT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + 8 * i);
-        const bf16x8 y = *reinterpret_cast<const bf16x8*>(b + 8 * i);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sd += (float)x[j] * (float)y[j];
-      }
+    for (int qt = 0; qt < NQT; ++qt) {
+      tq[qt] = load_tile(P.q + (qbase + qt * AT) * P.ldq + h * AD, P.ldq, P.Tq - qt * AT, tid);
+      td[qt] = load_tile(P.dout + (qbase + qt * AT) * P.ldo + h * AD, P.ldo, P.Tq - qt * AT, tid);
     }
-    sd += __shfl_xor(sd, 1, 64);
+    TileRegs tk = load_tile(P.k + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
+    TileRegs tv = load_tile(P.v + kbase * P.ldk + h * AD, P.ldk, P.Tk, tid);
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int qt = 0; qt < NQT; ++qt) {
+      const int q = qt * AT + 32 * w + (lane >> 1), half = lane & 1;
+      float sd = 0.f;
+      if (q < P.Tq) {
+        const bf16_t* a = P.dout + (qbase + q) * P.ldo + h * AD + 32 * half;
+        const bf16_t* b = P.o + (qbase + q) * P.ldo + h * AD + 32 * half;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ql = 16 * f + 4 * (lane >> 4) + r;          // row inside the wave's 32
-        dl4[f][r] = __shfl(sd, 2 * ql, 64);
-        const int q2 = 32 * w + ql;
-        lse4[f][r] = q2 < P.Tq ? P.lse[((int64_t)g * P.heads + h) * P.Tq + q2] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+          const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + 8 * i);
+          const bf16x8 y = *reinterpret_cast<const bf16x8*>(b + 8 * i);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sd += (float)x[j] * (float)y[j];
+        }
       }
+      sd += __shfl_xor(sd, 1, 64);
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = 16 * f + 4 * (lane >> 4) + r;          // row inside the wave's 32
+          dl4[qt][f][r] = __shfl(sd, 2 * ql, 64);
+          const int q2 = qt * AT + 32 * w + ql;
+          lse4[qt][f][r] = q2 < P.Tq ? P.lse[((int64_t)g * P.heads + h) * P.Tq + q2] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {     // (every global read of the prologue was requested before the first LDS write)
+      store_tile<false>(Qs + qt * TILE_B, tq[qt], tid);
+      store_tile<false>(dOs + qt * TILE_B, td[qt], tid);
+    }
+    store_tile<false>(Ks, tk, tid);
+    store_tile<false>(Vs, tv, tid);
+    if constexpr (NKT == 2) {
+      tk = load_tile(P.k + (kbase + AT) * P.ldk + h * AD, P.ldk, P.Tk - AT, tid);
+      tv = load_tile(P.v + (kbase + AT) * P.ldk + h * AD, P.ldk, P.Tk - AT, tid);
+      store_tile<false>(Ks + TILE_B, tk, tid);
+      store_tile<false>(Vs + TILE_B, tv, tid);
+    }
   }
-  store_tile<false>(Qs, tq, tid);      // (every global read of the prologue was requested before the first LDS write)
-  store_tile<false>(Ks, tk, tid);
-  store_tile<false>(Vs, tv, tid);
-  store_tile<false>(dOs, td, tid);
   __syncthreads();
 
   const float inv_keep = P.p > 0.f ? 1.0f / (1.0f - P.p) : 1.0f;
   const float* mrow = P.mask ? P.mask + kbase : nullptr;
-  // operands that stay in registers: the wave's 32 query rows of Q and dO (phase 1) and the transposed
+  // operands that stay in registers, per query tile: the wave's 32 query rows of Q and dO (phase 1) and the transposed
   // 16-column slices dO^T / Q^T [d = 16w ..][q] that dV / dK of every key chunk multiply (phase 2)
-  bf16x8 qa[2][2], da[2][2], oT[4], qT[4];
+  bf16x8 qa[NQT][2][2], da[NQT][2][2], oT[NQT][4], qT[NQT][4];
+  f32x4 aQ[NQT][4][2];
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
+  for (int qt = 0; qt < NQT; ++qt) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      qa[f][s] = frag_row64(Qs, 32 * w + 16 * f, s, lane);
-      da[f][s] = frag_row64(dOs, 32 * w + 16 * f, s, lane);
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        qa[qt][f][s] = frag_row64(Qs + qt * TILE_B, 32 * w + 16 * f, s, lane);
+        da[qt][f][s] = frag_row64(dOs + qt * TILE_B, 32 * w + 16 * f, s, lane);
+      }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      oT[qt][s] = frag_tr64(dOs + qt * TILE_B, 16 * w, s, lane);     // A[row = d][k = q]
+      qT[qt][s] = frag_tr64(Qs + qt * TILE_B, 16 * w, s, lane);
     }
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    oT[s] = frag_tr64(dOs, 16 * w, s, lane);     // A[row = d][k = q]
-    qT[s] = frag_tr64(Qs, 16 * w, s, lane);
+    for (int df = 0; df < 4; ++df)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) aQ[qt][df][f] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  f32x4 aQ[4][2];
-#pragma unroll
-  for (int df = 0; df < 4; ++df)
-#pragma unroll
-    for (int f = 0; f < 2; ++f) aQ[df][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- key chunks of 32: phase 1 (wave = 32 query rows) builds Pdrop^T and dS^T [key][q] of the chunk in LDS,
-  // phase 2 adds the chunk to dQ (wave = 32 queries) and finishes dV / dK of its 32 keys (wave = 16 columns)
+  // ---- key chunks of 32; per chunk the query tiles take turns: phase 1 (wave = 32 query rows) builds Pdrop^T and dS^T
+  // [key][q] of (chunk, query tile) in LDS, phase 2 adds them to dQ of that tile (wave = 32 queries) and to dV / dK of
+  // the chunk's 32 keys (wave = 16 columns), which are stored after the last query tile
   const int nchunks = (P.Tk + 31) >> 5;
   for (int c = 0; c < nchunks; ++c) {
-    f32x4 sS[2][2], sP[2][2];
+    f32x4 aV[2], aK[2];
 #pragma unroll
-    for (int k4 = 0; k4 < 2; ++k4)
+    for (int kf = 0; kf < 2; ++kf) { aV[kf] = f32x4{0.f, 0.f, 0.f, 0.f}; aK[kf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int f = 0; f < 2; ++f) { sS[k4][f] = f32x4{0.f, 0.f, 0.f, 0.f}; sP[k4][f] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int qt = 0; qt < NQT; ++qt) {
+      f32x4 sS[2][2], sP[2][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int k4 = 0; k4 < 2; ++k4)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) { sS[k4][f] = f32x4{0.f, 0.f, 0.f, 0.f}; sP[k4][f] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k4 = 0; k4 < 2; ++k4) {
+          const bf16x8 kb = frag_row64(Ks, 32 * c + 16 * k4, s, lane);
+          const bf16x8 vb = frag_row64(Vs, 32 * c + 16 * k4, s, lane);
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            sS[k4][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qt][f][s], kb, sS[k4][f], 0, 0, 0);   // D[q][key]
+            sP[k4][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[qt][f][s], vb, sP[k4][f], 0, 0, 0);
+          }
+        }
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
-        const bf16x8 kb = frag_row64(Ks, 32 * c + 16 * k4, s, lane);
-        const bf16x8 vb = frag_row64(Vs, 32 * c + 16 * k4, s, lane);
+        const int kl = 16 * k4 + (lane & 15), key = 32 * c + kl;
+        const float mk = (mrow && key < P.Tk) ? mrow[key] : 0.f;
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-          sS[k4][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[f][s], kb, sS[k4][f], 0, 0, 0);   // D[q][key]
-          sP[k4][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[f][s], vb, sP[k4][f], 0, 0, 0);
+          f32x4 pdv, dsv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qt * AT + 32 * w + 16 * f + 4 * (lane >> 4) + r;
+            float pr = 0.f, mult = 1.0f;
+            if (key < P.Tk && q < P.Tq) pr = __expf(sS[k4][f][r] * P.scale + mk - lse4[qt][f][r]);
+            if (P.p > 0.f) mult = dropout_mult(P.seed, (((uint64_t)g * P.heads + h) * P.Tq + q) * P.Tk + key, P.p, inv_keep);
+            pdv[r] = pr * mult;
+            dsv[r] = pr * (sP[k4][f][r] * mult - dl4[qt][f][r]);
+          }
+          const int ch = 4 * w + 2 * f + (lane >> 5);
+          const int o = off128(kl, ch) + ((lane >> 4) & 1) * 8;
+          store4(reinterpret_cast<bf16_t*>(PdT + o), pdv);
+          store4(reinterpret_cast<bf16_t*>(dST + o), dsv);
         }
       }
+      __syncthreads();
+      // dQ^T[d][q] += K^T[d][keys of the chunk] dS^T[keys][q]
+      {
+        bf16x8 tb[2];
 #pragma unroll
-    for (int k4 = 0; k4 < 2; ++k4) {
-      const int kl = 16 * k4 + (lane & 15), key = 32 * c + kl;
-      const float mk = (mrow && key < P.Tk) ? mrow[key] : 0.f;
+        for (int f = 0; f < 2; ++f) tb[f] = frag_tr128(dST, 32 * w + 16 * f, 0, lane);    // B[k = key][col = q]
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        f32x4 pdv, dsv;
+        for (int df = 0; df < 4; ++df) {
+          const bf16x8 ka2 = frag_tr64(Ks, 16 * df, c, lane);                              // A[row = d][k = key]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = 32 * w + 16 * f + 4 * (lane >> 4) + r;
-          float pr = 0.f, mult = 1.0f;
-          if (key < P.Tk && q < P.Tq) pr = __expf(sS[k4][f][r] * P.scale + mk - lse4[f][r]);
-          if (P.p > 0.f) mult = dropout_mult(P.seed, (((uint64_t)g * P.heads + h) * P.Tq + q) * P.Tk + key, P.p, inv_keep);
-          pdv[r] = pr * mult;
-          dsv[r] = pr * (sP[k4][f][r] * mult - dl4[f][r]);
+          for (int f = 0; f < 2; ++f) aQ[qt][df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka2, tb[f], aQ[qt][df][f], 0, 0, 0);
         }
-        const int ch = 4 * w + 2 * f + (lane >> 5);
-        const int o = off128(kl, ch) + ((lane >> 4) & 1) * 8;
-        store4(reinterpret_cast<bf16_t*>(PdT + o), pdv);
-        store4(reinterpret_cast<bf16_t*>(dST + o), dsv);
       }
-    }
-    __syncthreads();
-    // dQ^T[d][q] += K^T[d][keys of the chunk] dS^T[keys][q]
-    {
-      bf16x8 tb[2];
-#pragma unroll
-      for (int f = 0; f < 2; ++f) tb[f] = frag_tr128(dST, 32 * w + 16 * f, 0, lane);    // B[k = key][col = q]
-#pragma unroll
-      for (int df = 0; df < 4; ++df) {
-        const bf16x8 ka2 = frag_tr64(Ks, 16 * df, c, lane);                              // A[row = d][k = key]
-#pragma unroll
-        for (int f = 0; f < 2; ++f) aQ[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka2, tb[f], aQ[df][f], 0, 0, 0);
-      }
-    }
-    // dV^T / dK^T [d = 16w..][key of the chunk] = dO^T / Q^T [d][all q] x Pdrop / dS [q][key]
-    {
-      f32x4 aV[2], aK[2];
-#pragma unroll
-      for (int kf = 0; kf < 2; ++kf) { aV[kf] = f32x4{0.f, 0.f, 0.f, 0.f}; aK[kf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      // dV^T / dK^T [d = 16w..][key of the chunk] += dO^T / Q^T [d][q of this tile] x Pdrop / dS [q][key]
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf) {
           const bf16x8 pb = frag_row128(PdT, 16 * kf, s, lane);   // B[k = q][col = key]
           const bf16x8 sb = frag_row128(dST, 16 * kf, s, lane);
-          aV[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oT[s], pb, aV[kf], 0, 0, 0);
-          aK[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[s], sb, aK[kf], 0, 0, 0);
+          aV[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oT[qt][s], pb, aV[kf], 0, 0, 0);
+          aK[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[qt][s], sb, aK[kf], 0, 0, 0);
         }
-      const int dcol = h * AD + 16 * w + 4 * (lane >> 4);
-#pragma unroll
-      for (int kf = 0; kf < 2; ++kf) {
-        const int key = 32 * c + 16 * kf + (lane & 15);
-        if (key < P.Tk) {
-          store4(P.dv + (kbase + key) * P.ldk + dcol, aV[kf]);
-          f32x4 t = aK[kf];
-          t[0] *= P.scale; t[1] *= P.scale; t[2] *= P.scale; t[3] *= P.scale;
-          store4(P.dk + (kbase + key) * P.ldk + dcol, t);
-        }
-      }
+      __syncthreads();   // the chunk images are rewritten by the next query tile / chunk
     }
-    __syncthreads();   // the chunk images are rewritten by the next chunk
-  }
+    const int dcol = h * AD + 16 * w + 4 * (lane >> 4);
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int x = 32 * w + 16 * f + (lane & 15);
-    if (x < P.Tq) {
-      const int dcol = h * AD + 4 * (lane >> 4);
-#pragma unroll
-      for (int df = 0; df < 4; ++df) {
-        f32x4 t = aQ[df][f];
+    for (int kf = 0; kf < 2; ++kf) {
+      const int key = 32 * c + 16 * kf + (lane & 15);
+      if (key < P.Tk) {
+        store4(P.dv + (kbase + key) * P.ldk + dcol, aV[kf]);
+        f32x4 t = aK[kf];
         t[0] *= P.scale; t[1] *= P.scale; t[2] *= P.scale; t[3] *= P.scale;
-        store4(P.dq + (qbase + x) * P.ldq + dcol + 16 * df, t);
+        store4(P.dk + (kbase + key) * P.ldk + dcol, t);
       }
     }
   }
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int x = qt * AT + 32 * w + 16 * f + (lane & 15);
+      if (x < P.Tq) {
+        const int dcol = h * AD + 4 * (lane >> 4);
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+          f32x4 t = aQ[qt][df][f];
+          t[0] *= P.scale; t[1] *= P.scale; t[2] *= P.scale; t[3] *= P.scale;
+          store4(P.dq + (qbase + x) * P.ldq + dcol + 16 * df, t);
+        }
+      }
+    }
 }
+
+__global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(AttnMfmaParams P) { attn_mfma_bwd_body<1, 1>(P); }
+__global__ __launch_bounds__(256, 1) void attn_mfma_bwd256_kernel(AttnMfmaParams P) { attn_mfma_bwd_body<2, 2>(P); }
 
 // =========================================================================================
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -420,15 +470,24 @@ extern "C" int fcmf_attn_mfma_fwd(const void* q, const void* k, const void* v, c
                                   int G, int heads, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
                                   float dropout_p, uint64_t seed, void* stream) {
   if (!q || !k || !v || !out || G <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0) return FCMF_ERR_ARG;
-  if (Tk > AT || ldq % 8 || ldk % 8 || ldo % 4 || !al16(q) || !al16(k) || !al16(v) || !al16(out)) return FCMF_ERR_UNSUPPORTED;
+  if (Tk > 2 * AT || ldq % 8 || ldk % 8 || ldo % 4 || !al16(q) || !al16(k) || !al16(v) || !al16(out)) return FCMF_ERR_UNSUPPORTED;
   AttnMfmaParams P{};
   P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.mask = mask; P.out = (bf16_t*)out; P.lse = lse;
   P.G = G; P.heads = heads; P.Tq = Tq; P.Tk = Tk; P.ldq = ldq; P.ldk = ldk; P.ldo = ldo;
   P.scale = scale; P.p = dropout_p; P.seed = seed;
+  const dim3 grid(G * heads, (Tq + AT - 1) / AT);
+  if (Tk > AT) {
+    const int smem = 4 * TILE_B;
+    static bool attr2 = false;
+    if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_fwd256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr2 = true; }
+    hipLaunchKernelGGL(attn_mfma_fwd256_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+    FCMF_CHECK_LAUNCH();
+    return FCMF_OK;
+  }
   const int smem = 2 * TILE_B;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-  hipLaunchKernelGGL(attn_mfma_fwd_kernel, dim3(G * heads, (Tq + AT - 1) / AT), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+  hipLaunchKernelGGL(attn_mfma_fwd_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
@@ -438,7 +497,7 @@ extern "C" int fcmf_attn_mfma_bwd(const void* q, const void* k, const void* v, c
                                   int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldo, float scale, float dropout_p,
                                   uint64_t seed, void* stream) {
   if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || G <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0) return FCMF_ERR_ARG;
-  if (Tk > AT || Tq > AT || ldq % 8 || ldk % 8 || ldo % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(out) || !al16(dout) ||
+  if (Tk > 2 * AT || Tq > 2 * AT || ldq % 8 || ldk % 8 || ldo % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(out) || !al16(dout) ||
       !al16(dq) || !al16(dk) || !al16(dv))
     return FCMF_ERR_UNSUPPORTED;
   AttnMfmaParams P{};
@@ -446,6 +505,14 @@ extern "C" int fcmf_attn_mfma_bwd(const void* q, const void* k, const void* v, c
   P.dout = (const bf16_t*)dout; P.lse = const_cast<float*>(lse); P.dq = (bf16_t*)dq; P.dk = (bf16_t*)dk; P.dv = (bf16_t*)dv;
   P.G = G; P.heads = heads; P.Tq = Tq; P.Tk = Tk; P.ldq = ldq; P.ldk = ldk; P.ldo = ldo;
   P.scale = scale; P.p = dropout_p; P.seed = seed;
+  if (Tk > AT || Tq > AT) {
+    const int smem = 9 * TILE_B;   // 2 x (Q, dO) + 2 x (K, V) tiles + the two 8 KiB chunk images = 144 KiB: one workgroup per CU
+    static bool attr2 = false;
+    if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_bwd256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr2 = true; }
+    hipLaunchKernelGGL(attn_mfma_bwd256_kernel, dim3(G * heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+    FCMF_CHECK_LAUNCH();
+    return FCMF_OK;
+  }
   const int smem = 5 * TILE_B;   // Q, K, V, dO tiles + the two 8 KiB chunk images = 80 KiB: two workgroups per CU
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }

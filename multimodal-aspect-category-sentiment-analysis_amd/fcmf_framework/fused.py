@@ -117,7 +117,7 @@ class _SideGemms:
 # self-attention over a fused [G,T,3H] q|k|v buffer
 # --------------------------------------------------------------------------------------
 def _use_mfma(dtype, Hd, heads, T):
-    return dtype == torch.bfloat16 and Hd // heads == 64 and T <= 128 and ops.USE_MFMA_ATTENTION
+    return dtype == torch.bfloat16 and Hd // heads == 64 and T <= 256 and ops.USE_MFMA_ATTENTION
 
 
 def _qkv_desc(qkv, G, T, Hd, heads, mask, scale, p, seed):

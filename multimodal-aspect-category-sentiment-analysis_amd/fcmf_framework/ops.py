@@ -791,9 +791,9 @@ class AttentionFn(torch.autograd.Function):
         G, R, HD = q.shape
         out = torch.empty((G, R, HD), dtype=q.dtype, device=q.device)
         lse = torch.empty((G, heads, R), dtype=torch.float32, device=q.device)
-        # text-encoder shape (bf16, head dim 64, <=128 keys, plain mask): MFMA kernel
+        # text-encoder shape (bf16, head dim 64, <=256 queries / keys, plain mask): MFMA kernel
         mfma = (q.dtype == torch.bfloat16 and HD // heads == 64 and k2 is None and bias is None and not causal
-                and k1 is not None and k1.shape[1] <= 128 and R <= 128 and q.is_contiguous() and k1.is_contiguous()
+                and k1 is not None and k1.shape[1] <= 256 and R <= 256 and q.is_contiguous() and k1.is_contiguous()
                 and v1.is_contiguous() and USE_MFMA_ATTENTION)
         if mfma:
             H.check(H.lib().fcmf_attn_mfma_fwd(H.ptr(q), H.ptr(k1), H.ptr(v1), H.ptr(mask), H.ptr(out), H.ptr(lse), G, heads,

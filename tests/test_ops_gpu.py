@@ -660,7 +660,7 @@ def test_bertadam_matches_golden(dev):
 
 
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("Tq,Tk", [(128, 128), (77, 128), (128, 50), (33, 17)])
+@pytest.mark.parametrize("Tq,Tk", [(128, 128), (77, 128), (128, 50), (33, 17), (256, 256), (200, 256), (256, 150), (130, 129)])
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_attention_mfma_matches_reference_and_valu_kernel(dev, Tq, Tk, p):
     """bf16 / head-dim-64 text-encoder attention on the MFMA kernel: against the fp64 reference
