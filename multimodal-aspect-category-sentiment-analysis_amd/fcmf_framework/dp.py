@@ -205,11 +205,12 @@ class GradReducer:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main)
         for w, buf in self._work:
-            w.wait()
             if cuda:
                 with torch.cuda.stream(self._stream):
+                    w.wait()                  # (RCCL: makes the SIDE stream wait for the collective, not the host)
                     buf.div_(self.world)
             else:
+                w.wait()
                 buf.div_(self.world)
         if cuda:
             main.wait_stream(self._stream)

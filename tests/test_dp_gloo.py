@@ -114,3 +114,41 @@ def test_grad_reducer_two_ranks_gloo():
     for rank, err, nb, dead_ok in res:
         assert err < 1e-6, (rank, err)
         assert nb > 1 and dead_ok
+
+
+def test_grad_arena_layout_for_fcmf_model():
+    """GradArena.for_model on the real FCMF module tree (CPU construction): the text encoder's pooler is left out, every
+    other parameter has a 256-byte-aligned slice, and the q|k|v weights / biases of each fused attention block are
+    adjacent in that order (one [3H, H] weight-gradient GEMM writes them), in backward (reverse registration) order"""
+    sys.path.insert(0, PKG)
+    import tempfile
+    import synthetic_data as synth
+    from fcmf_framework.dp import ALIGN, GradArena
+    from fcmf_framework.fcmf_multimodal import FCMF
+    from fcmf_framework.fused import QKVStorageMixin
+    from fcmf_framework.roberta import RobertaConfig, RobertaModel
+    d = tempfile.mkdtemp()
+    RobertaModel(RobertaConfig(**synth.TINY_CFG)).save_pretrained(d)
+    model = FCMF(d, num_imgs=2, num_roi=3)
+    arena = GradArena.for_model(model)
+    try:
+        named = dict(model.named_parameters())
+        in_arena = {id(p) for p in arena.order}
+        assert all(("bert.cell.pooler" in n) != (id(p) in in_arena) for n, p in named.items())
+        assert arena.total * 4 >= sum(p.numel() for p in arena.order) * 4 and arena.flat.numel() == arena.total
+        nblocks = 0
+        for m in model.modules():
+            if isinstance(m, QKVStorageMixin):
+                nblocks += 1
+                for trio in ((m.query.weight, m.key.weight, m.value.weight), (m.query.bias, m.key.bias, m.value.bias)):
+                    offs = [arena.offset[id(p)] for p in trio]
+                    assert offs[0] % ALIGN == 0 and offs[1] == offs[0] + trio[0].numel() and offs[2] == offs[1] + trio[1].numel()
+                    blk = arena.take_block(list(trio))
+                    assert blk is not None and blk.numel() == 3 * trio[0].numel() and arena.take_block(list(trio)) is None
+        assert nblocks >= synth.TINY_CFG["num_hidden_layers"] + 2          # text encoder layers + text2img + mm_attention
+        # backward order: the classifier (registered last) comes first, the word embeddings last
+        assert arena.offset[id(named["classifier.weight"])] < arena.offset[id(named["encoder.bert.cell.embeddings.word_embeddings.weight"])]
+        arena.zero()
+        assert all(p.grad is None for p in arena.order)
+    finally:
+        arena.deactivate()
