@@ -15,6 +15,7 @@
 // One LDS image per tile serves both row reads (ds_read_b128) and transposed reads
 // (ds_read_b64_tr_b16); swizzles verified conflict-free with tools/lds_conflicts.py.
 #include "common.h"
+#include <cstdlib>
 
 constexpr int AD = 64;             // head dim
 constexpr int AT = 128;            // tile rows (queries / keys)
@@ -134,22 +135,8 @@ struct AttnMfmaParams {
 // NKT = 128-key tiles per (sequence, head): 1 (Tk <= 128: 32 KiB of LDS, three workgroups per CU) or 2 (Tk <= 256: the
 // FCMF-large text encoder, 64 KiB, two per CU).  The images of the second tile lie right behind the first (row r of the
 // 256-row image = row r - 128 of the second tile: the swizzle keys only use row bits 1..3).
-template <int NKT>
-__device__ __forceinline__ void attn_mfma_fwd_body(const AttnMfmaParams& P) {
-  constexpr int NKF = 8 * NKT;       // 16-key fragments
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;
-  char* Vs = smem + NKT * TILE_B;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
-  const int q0 = blockIdx.y * AT + w * 32;
-  const bf16_t* kbase_p = P.k + (int64_t)g * P.Tk * P.ldk + h * AD;
-  const bf16_t* vbase_p = P.v + (int64_t)g * P.Tk * P.ldk + h * AD;
-  const TileRegs kt = load_tile(kbase_p, P.ldk, P.Tk, tid);
-  const TileRegs vt = load_tile(vbase_p, P.ldk, P.Tk, tid);
-
-  // Q fragments straight from global memory in operand layout (16 B per lane)
-  bf16x8 qf[2][2];
+// Q fragments of the wave's 32 query rows straight from global memory in operand layout (16 B per lane)
+__device__ __forceinline__ void load_q_frags(const AttnMfmaParams& P, int g, int h, int q0, int lane, bf16x8 (&qf)[2][2]) {
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -159,16 +146,16 @@ __device__ __forceinline__ void attn_mfma_fwd_body(const AttnMfmaParams& P) {
       if (row < P.Tq) v = *reinterpret_cast<const uint4*>(P.q + ((int64_t)g * P.Tq + row) * P.ldq + h * AD + 32 * s + 8 * (lane >> 4));
       qf[f][s] = *reinterpret_cast<bf16x8*>(&v);
     }
-  store_tile<false>(Ks, kt, tid);      // (all of K, V and Q were requested before the first LDS write)
-  store_tile<true>(Vs, vt, tid);
-  if constexpr (NKT == 2) {
-    const TileRegs kt2 = load_tile(kbase_p + (int64_t)AT * P.ldk, P.ldk, P.Tk - AT, tid);
-    const TileRegs vt2 = load_tile(vbase_p + (int64_t)AT * P.ldk, P.ldk, P.Tk - AT, tid);
-    store_tile<false>(Ks + TILE_B, kt2, tid);
-    store_tile<true>(Vs + TILE_B, vt2, tid);
-  }
-  __syncthreads();
+}
 
+// one (sequence, head, 128-query tile) from the staged K / V images: scores, softmax, dropout, P V, store
+// (mask_lds != NULL: the additive key mask of the tile was staged in LDS with K / V -- the persistent kernel must not issue a
+// global load inside the tile: the counter of vector-memory operations retires in order, so waiting for it would also wait
+// for the next tile's operands that are in flight behind it)
+template <int NKT>
+__device__ __forceinline__ void attn_mfma_fwd_tile(const AttnMfmaParams& P, int g, int h, int q0, int lane, const bf16x8 (&qf)[2][2],
+                                                   const char* Ks, const char* Vs, const float* mask_lds = nullptr) {
+  constexpr int NKF = 8 * NKT;       // 16-key fragments
   // S^T[key][q]: NKF key fragments x 2 query fragments
   f32x4 sc[NKF][2];
 #pragma unroll
@@ -196,7 +183,7 @@ __device__ __forceinline__ void attn_mfma_fwd_body(const AttnMfmaParams& P) {
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * kf + 4 * (lane >> 4) + r;
         float s = -INFINITY;
-        if (key < P.Tk) s = sc[kf][f][r] * P.scale + (mrow ? mrow[key] : 0.f);
+        if (key < P.Tk) s = sc[kf][f][r] * P.scale + (mask_lds ? mask_lds[key] : (mrow ? mrow[key] : 0.f));
         sc[kf][f][r] = s;
         m = fmaxf(m, s);
       }
@@ -252,6 +239,92 @@ __device__ __forceinline__ void attn_mfma_fwd_body(const AttnMfmaParams& P) {
 #pragma unroll
       for (int df = 0; df < 4; ++df) store4(orow + 16 * df, oc[df][f]);
     }
+  }
+}
+
+template <int NKT>
+__device__ __forceinline__ void attn_mfma_fwd_body(const AttnMfmaParams& P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + NKT * TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = blockIdx.x / P.heads, h = blockIdx.x % P.heads;
+  const int q0 = blockIdx.y * AT + w * 32;
+  const bf16_t* kbase_p = P.k + (int64_t)g * P.Tk * P.ldk + h * AD;
+  const bf16_t* vbase_p = P.v + (int64_t)g * P.Tk * P.ldk + h * AD;
+  const TileRegs kt = load_tile(kbase_p, P.ldk, P.Tk, tid);
+  const TileRegs vt = load_tile(vbase_p, P.ldk, P.Tk, tid);
+  bf16x8 qf[2][2];
+  load_q_frags(P, g, h, q0, lane, qf);
+  store_tile<false>(Ks, kt, tid);      // (all of K, V and Q were requested before the first LDS write)
+  store_tile<true>(Vs, vt, tid);
+  if constexpr (NKT == 2) {
+    const TileRegs kt2 = load_tile(kbase_p + (int64_t)AT * P.ldk, P.ldk, P.Tk - AT, tid);
+    const TileRegs vt2 = load_tile(vbase_p + (int64_t)AT * P.ldk, P.ldk, P.Tk - AT, tid);
+    store_tile<false>(Ks + TILE_B, kt2, tid);
+    store_tile<true>(Vs + TILE_B, vt2, tid);
+  }
+  __syncthreads();
+  attn_mfma_fwd_tile<NKT>(P, g, h, q0, lane, qf, Ks, Vs);
+}
+
+// Persistent form for Tk <= 128 (the FCMF-base text encoder: 4608 (sequence, head) tiles per layer): a workgroup walks
+// tiles blockIdx.x, + gridDim.x, ...; the K / V / Q loads of the NEXT tile are put in flight (into registers) before the
+// current tile is computed and land in the other half of a double-buffered LDS image afterwards, so the global-load
+// latency -- 58 % of a wave's lifetime in the one-tile-per-workgroup kernel (SQ_WAIT_ANY) -- hides under the softmax.
+// 64 KiB of LDS, two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void attn_mfma_fwd_persist_kernel(AttnMfmaParams P, int ntiles, int qtiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  auto where = [&](int tile, int& g, int& h, int& q0) {
+    const int gh = tile / qtiles;
+    g = gh / P.heads; h = gh - g * P.heads; q0 = (tile - gh * qtiles) * AT + w * 32;
+  };
+  constexpr int BUF = 2 * TILE_B + 512;      // K image, V image, 128 mask floats
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  int g, h, q0;
+  where(tile, g, h, q0);
+  bf16x8 qf[2][2];
+  auto mask_of = [&](int gg) { return (P.mask && tid < P.Tk) ? P.mask[(int64_t)gg * P.Tk + tid] : 0.f; };
+  {
+    const TileRegs kt = load_tile(P.k + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
+    const TileRegs vt = load_tile(P.v + (int64_t)g * P.Tk * P.ldk + h * AD, P.ldk, P.Tk, tid);
+    const float mv = mask_of(g);
+    load_q_frags(P, g, h, q0, lane, qf);
+    store_tile<false>(smem, kt, tid);
+    store_tile<true>(smem + TILE_B, vt, tid);
+    if (tid < AT) reinterpret_cast<float*>(smem + 2 * TILE_B)[tid] = mv;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (;;) {
+    const int nxt = tile + gridDim.x;
+    const bool more = nxt < ntiles;
+    int g2 = g, h2 = h, q2 = q0;
+    TileRegs kt, vt;
+    bf16x8 qn[2][2];
+    float mv = 0.f;
+    if (more) {                              // next tile's operands: in flight under this tile's arithmetic
+      where(nxt, g2, h2, q2);
+      kt = load_tile(P.k + (int64_t)g2 * P.Tk * P.ldk + h2 * AD, P.ldk, P.Tk, tid);
+      vt = load_tile(P.v + (int64_t)g2 * P.Tk * P.ldk + h2 * AD, P.ldk, P.Tk, tid);
+      mv = mask_of(g2);
+      load_q_frags(P, g2, h2, q2, lane, qn);
+    }
+    const char* buf = smem + cur * BUF;
+    attn_mfma_fwd_tile<1>(P, g, h, q0, lane, qf, buf, buf + TILE_B, reinterpret_cast<const float*>(buf + 2 * TILE_B));
+    if (!more) break;
+    cur ^= 1;                                // (the other buffer was last read before the previous barrier)
+    store_tile<false>(smem + cur * BUF, kt, tid);
+    store_tile<true>(smem + cur * BUF + TILE_B, vt, tid);
+    if (tid < AT) reinterpret_cast<float*>(smem + cur * BUF + 2 * TILE_B)[tid] = mv;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) qf[f][s2] = qn[f][s2];
+    g = g2; h = h2; q0 = q2; tile = nxt;
+    __syncthreads();
   }
 }
 
@@ -481,6 +554,16 @@ extern "C" int fcmf_attn_mfma_fwd(const void* q, const void* k, const void* v, c
     static bool attr2 = false;
     if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_fwd256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr2 = true; }
     hipLaunchKernelGGL(attn_mfma_fwd256_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+    FCMF_CHECK_LAUNCH();
+    return FCMF_OK;
+  }
+  const int ntiles = (int)(grid.x * grid.y);
+  static const bool no_persist = getenv("FCMF_ATTN_NO_PERSIST") != nullptr;      // A/B switch for benchmarks
+  if (ntiles >= 4 * 512 && !no_persist) {       // enough tiles for every resident workgroup (2 per CU) to walk several
+    const int smem = 2 * (2 * TILE_B + 512);
+    static bool attr3 = false;
+    if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_fwd_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr3 = true; }
+    hipLaunchKernelGGL(attn_mfma_fwd_persist_kernel, dim3(512), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P, ntiles, (int)grid.y);
     FCMF_CHECK_LAUNCH();
     return FCMF_OK;
   }

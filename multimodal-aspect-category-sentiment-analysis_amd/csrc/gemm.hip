@@ -333,15 +333,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 // allocation of the main loop clean (2 waves/SIMD -> 256 VGPRs, 128 of them accumulators).
 // =========================================================================================
 constexpr int GB = 256;                       // block tile rows and columns
-constexpr int A_TILE_BYTES = GB * BK * 2;     // 16 KiB per operand tile
-constexpr int TSTAGE_BYTES = 2 * A_TILE_BYTES;
-constexpr int TNST = 4;
+constexpr int RING_BYTES = 128 * 1024;        // operand ring: 4 stages of 32-deep k-tiles or 2 stages of 64-deep k-tiles
 
-template <bool TR>
+// Image of a K-contiguous operand tile with 64-deep k-tiles [256 rows][64 k] (128-B rows = whole cache lines):
+// 16-B chunk c (0..7) stored at c ^ ((row >> 1) & 7): the ds_read_b128 fragment reads of either k-half are
+// conflict free (tools/lds_conflicts.py).
+__device__ __forceinline__ int swz_row64(int r) { return (r >> 1) & 7; }
+
+// per-lane source offset of DMA piece `piece` (1 KiB of the operand tile's LDS image) for k-tile 0.
+//  KB = 32: K-contiguous tile = 16 rows x 64 B per piece; transposed tile = 2 k-rows x 512 B per piece.
+//  KB = 64: K-contiguous tile = 8 rows x 128 B per piece (every 128-B line is fetched by ONE wave instruction:
+//           with 64-B row pieces the CU's L2->L1 path moves each line twice, measured 1.5x slower);
+//           transposed tile as for KB = 32 with 64 k-rows.
+template <bool TR, int KB>
 __device__ __forceinline__ unsigned dma_voffset_t(int piece, int lane, int64_t ld, int x0, int xdim) {
-  const int q = piece * 64 + lane;             // 16-B slot inside the 16 KiB operand tile (1024 slots)
-  if (!TR) {
+  const int q = piece * 64 + lane;             // 16-B slot inside the operand tile
+#ifdef FCMF_GEMM_ABLATE_LINE   // diagnostic (DMA stream alone): K-contiguous operands fetched as 128 rows x 128 B (whole cache
+  if (!TR && KB == 32) {        // lines, each once) per k-tile instead of 256 rows x 64 B; odd k-tiles take rows 128..255
+    const int row = q >> 3, c = q & 7;
+    if (x0 + row >= xdim) return 0x80000000u;
+    return (unsigned)(((int64_t)(x0 + row) * ld + c * 8) * 2);
+  }
+#endif
+  if (!TR && KB == 32) {
     const int row = q >> 2, c = (q & 3) ^ swz_row(row);
+    if (x0 + row >= xdim) return 0x80000000u;
+    return (unsigned)(((int64_t)(x0 + row) * ld + c * 8) * 2);
+  } else if (!TR) {
+    const int row = q >> 3, c = (q & 7) ^ swz_row64(row);
     if (x0 + row >= xdim) return 0x80000000u;
     return (unsigned)(((int64_t)(x0 + row) * ld + c * 8) * 2);
   } else {
@@ -367,20 +386,28 @@ __device__ __forceinline__ void store8f(float* q, const f32x2 (&v)[4]) {
 // MI = 16-row fragments per wave along M: 8 -> 256x256 block tile, 6 -> 192x256 (row-major A only).  The
 // 192-row variant exists for tile-count quantisation: M = 49152, N = 768 gives 576 tiles of 256 rows (2.25
 // rounds on 256 CUs, the last one a quarter full) but 768 tiles of 192 rows = exactly 3 rounds of 3/4 the work.
-template <bool A_TR, bool B_TR, typename TC, int EPI, int MI>
+// KB = depth of a k-tile: 32 (4-stage ring, three k-tiles in flight) or 64 (2-stage ring, ONE k-tile in flight, half
+// the barriers; K-contiguous operands then arrive as whole 128-B lines -- see dma_voffset_t).
+template <bool A_TR, bool B_TR, typename TC, int EPI, int MI, int KB>
 __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   static_assert(MI == 8 || (MI == 6 && !A_TR && sizeof(TC) == 2), "192-row tiles: row-major A, bf16 output");
+  static_assert(KB == 32 || KB == 64, "k-tile depth");
   constexpr int NW = 8;
   constexpr int TM = 32 * MI;                  // block tile rows
   constexpr int WM = 16 * MI;                  // rows per wave
-  constexpr int A_PIECES = 2, B_PIECES = 2;    // 1 KiB DMA pieces per wave per operand tile (A: see na_pieces)
+  constexpr int A_TILE_BYTES = GB * KB * 2;    // LDS bytes per operand tile (the 192-row A tile leaves a quarter unused)
+  constexpr int TSTAGE_BYTES = 2 * A_TILE_BYTES;
+  constexpr int TNST = RING_BYTES / TSTAGE_BYTES;   // 4 or 2
+  constexpr int NH = KB / 32;                  // 32-deep halves of a k-tile (MFMA k = 32)
+  constexpr int A_PIECES = KB / 16, B_PIECES = KB / 16;   // 1 KiB DMA pieces per wave per operand tile (A: see na_pieces)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;     // rows wm*WM, cols wn*64
-  // the 12 KiB A tile of the 192-row variant is 12 pieces: two for waves 0-3, one (pieces 8..11) for waves 4-7
-  const int na_pieces = (MI == 8 || wave < 4) ? 2 : 1;
-  const int a_piece0 = (MI == 8 || wave < 4) ? wave * 2 : 4 + wave;
+  // the A tile of the 192-row variant: 12 pieces at KB = 32 (two for waves 0-3, one -- pieces 8..11 -- for waves 4-7),
+  // 24 pieces at KB = 64 (three per wave)
+  const int na_pieces = MI == 8 ? A_PIECES : (KB == 64 ? 3 : (wave < 4 ? 2 : 1));
+  const int a_piece0 = MI == 8 ? wave * A_PIECES : (KB == 64 ? wave * 3 : (wave < 4 ? wave * 2 : 4 + wave));
 
   // XCD-aware order inside a round: the workgroups of one XCD (blockIdx % 8) take consecutive logical
   // items, and consecutive items share the A row-panel (all N tiles of one M tile) -> L2 hits.
@@ -391,32 +418,34 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     int q = nblk >> 3, r = nblk & 7, xcd = slot & 7, local = slot >> 3;
     slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int nk_total = (p.K + BK - 1) / BK;
+  const int nk_total = (p.K + KB - 1) / KB;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
-  const unsigned a_step = A_TR ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
-  const unsigned b_step = B_TR ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
+  const unsigned a_step = A_TR ? (unsigned)(KB * p.lda * 2) : (unsigned)(KB * 2);
+  const unsigned b_step = B_TR ? (unsigned)(KB * p.ldb * 2) : (unsigned)(KB * 2);
   // Per-lane LDS offsets are computed ONCE; fragment f of a K-contiguous operand is a constant 1 KiB
   // step away (row bit 3, which drives the swizzle, does not depend on f).
   typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
   const int rowl = lane & 15, g4 = lane >> 4, q4 = rowl >> 2, p4 = rowl & 3;
-  const int row_base = rowl * 64 + ((g4 ^ swz_row(rowl)) << 4);
+  // K-contiguous image: rows of 2*KB bytes; at KB = 64 the k-half h flips bit 2 of the (swizzled) chunk index = bit 6 of
+  // the byte offset.  Transposed image: 512-B k-rows, k-half h is 32 rows = 16 KiB further (tr_key(k + 32) == tr_key(k)).
+  const int row_base = KB == 32 ? rowl * 64 + ((g4 ^ swz_row(rowl)) << 4) : rowl * 128 + ((g4 ^ swz_row64(rowl)) << 4);
   const int trk = tr_key(8 * g4 + q4);
   const int tr_col = ((p4 >> 1) << 4) + ((p4 & 1) << 3);
-  const int a_lane = A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * WM * 64;
-  const int b_lane = A_TILE_BYTES + (B_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wn * 64 * 64);
-  auto frag_a = [&](const char* st, int f) -> bf16x8 {     // f = 0..MI-1: 16-row fragment of this wave's rows
-    if (!A_TR) return *reinterpret_cast<const bf16x8*>(st + a_lane + f * 1024);
-    const char* q = st + a_lane + (((wm * 8 + f) ^ trk) << 5);
+  const int a_lane = A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * WM * (2 * KB);
+  const int b_lane = A_TILE_BYTES + (B_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wn * 64 * (2 * KB));
+  auto frag_a = [&](const char* st, int f, int h) -> bf16x8 {     // f = 0..MI-1: 16-row fragment of this wave's rows
+    if (!A_TR) return *reinterpret_cast<const bf16x8*>(st + (a_lane ^ (h << 6)) + f * (32 * KB));
+    const char* q = st + a_lane + (((wm * 8 + f) ^ trk) << 5) + h * 16384;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * 512));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
   };
-  auto frag_b = [&](const char* st, int f) -> bf16x8 {     // f = 0..3
-    if (!B_TR) return *reinterpret_cast<const bf16x8*>(st + b_lane + f * 1024);
-    const char* q = st + b_lane + (((wn * 4 + f) ^ trk) << 5);
+  auto frag_b = [&](const char* st, int f, int h) -> bf16x8 {     // f = 0..3
+    if (!B_TR) return *reinterpret_cast<const bf16x8*>(st + (b_lane ^ (h << 6)) + f * (32 * KB));
+    const char* q = st + b_lane + (((wn * 4 + f) ^ trk) << 5) + h * 16384;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * 512));
     bf16x8 r;
@@ -444,9 +473,9 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     return r;
 #endif
 #pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR>(a_piece0 + j, lane, p.lda, w.i0, p.M);
+    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR, KB>(a_piece0 + j, lane, p.lda, w.i0, p.M);
 #pragma unroll
-    for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
+    for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR, KB>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
     return r;
   };
   // DMA of k-tile t of item w into ring stage s
@@ -458,7 +487,13 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 #ifdef FCMF_GEMM_ABLATE_SRC      // diagnostic build: every DMA piece re-reads the SAME first 1 KiB of its operand (L1 hits)
     const unsigned ka = 0, kb = 0;
 #else
+#ifdef FCMF_GEMM_ABLATE_LINE
+    const int tt = w.kt_begin + t;
+    const unsigned ka = A_TR ? (unsigned)tt * a_step : (unsigned)(tt >> 1) * 128u + (unsigned)(tt & 1) * 128u * (unsigned)p.lda * 2u;
+    const unsigned kb = B_TR ? (unsigned)tt * b_step : (unsigned)(tt >> 1) * 128u + (unsigned)(tt & 1) * 128u * (unsigned)p.ldb * 2u;
+#else
     const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
+#endif
 #endif
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
@@ -485,17 +520,20 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   const Item w = decode(item);
   Src src = sources(w);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(src.a[j]), "+v"(src.b[j]));   // materialised here, not re-derived per k-tile
+  for (int j = 0; j < A_PIECES; ++j) asm volatile("" : "+v"(src.a[j]), "+v"(src.b[j]));   // materialised here, not re-derived per k-tile
   const int i0 = w.i0, j0 = w.j0, nkt = w.nkt;
   [[maybe_unused]] const int stamp_item = (item - slot) / nblk;
+  [[maybe_unused]] unsigned long long stamp_cyc0 = 0;
   FCMF_STAMP(0);
   // Issue schedule: tiles 0, 1, 2 before the loop (or already in flight from the previous epilogue), tile t + 3
   // after barrier t.  Own DMAs of tile t have landed once at most the two younger tiles (4 DMAs each) are
   // outstanding: loads retire in order, and stores of the previous epilogue that are still in flight only
   // make the wait longer.
+  // (KB = 64: ONE k-tile in flight -- tile t + 1 is issued after barrier t and has landed at vmcnt(0).)
   auto wait_landed = [&](int t, auto per_tile) {
     constexpr int PT = decltype(per_tile)::value;   // DMAs per k-tile of this wave: 4, or 3 for waves 4-7 of the 192-row tile
     const int younger = nkt - 1 - t;
+    if constexpr (KB == 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
 #ifdef FCMF_GEMM_DEPTH2        // diagnostic build: two k-tiles in flight instead of three (prefetch-depth sensitivity)
     if (younger >= 1) { if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -506,6 +544,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto issue_after_barrier = [&](int t) {
+    if constexpr (KB == 64) { if (t + 1 < nkt) issue(w, src, t + 1, base + t + 1); return; }
 #ifdef FCMF_GEMM_DEPTH2
     if (t + 2 < nkt) issue(w, src, t + 2, base + t + 2);
     return;
@@ -523,15 +562,15 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   for (int f = 0; f < MI; ++f) fa[f] = bf16x8{};
   for (int f = 0; f < 4; ++f) fb[f] = bf16x8{};
 #endif
-  auto load_frags = [&](int t) {
+  auto load_frags = [&](int t, int h) {     // h: 32-deep half of the k-tile (always 0 at KB = 32)
 #ifdef FCMF_GEMM_ABLATE_FRAGS    // diagnostic build (with ABLATE_MMA): no fragment reads either -> the DMA stream alone
     return;
 #endif
     const char* st = stage_at(base + t);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) fb[f] = frag_b(st, f);
+    for (int f = 0; f < 4; ++f) fb[f] = frag_b(st, f, h);
 #pragma unroll
-    for (int f = 0; f < MI; ++f) fa[f] = frag_a(st, f);
+    for (int f = 0; f < MI; ++f) fa[f] = frag_a(st, f, h);
   };
   auto mma = [&]() {
 #ifdef FCMF_GEMM_ABLATE_MMA      // diagnostic build: feed only (fragments stay live, no matrix instructions)
@@ -551,10 +590,12 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 
   if (!pre) {
     issue(w, src, 0, base);
-    if (1 < nkt) issue(w, src, 1, base + 1);
+    if constexpr (KB == 32) {
+      if (1 < nkt) issue(w, src, 1, base + 1);
 #ifndef FCMF_GEMM_DEPTH2
-    if (2 < nkt) issue(w, src, 2, base + 2);
+      if (2 < nkt) issue(w, src, 2, base + 2);
 #endif
+    }
   }
   // aux operand of the epilogue (gelu' argument / residual), row layout: 16 B per lane, 8 rows of the wave's
   // 128x64 sub-tile per instruction, 4 instructions per 32-row round.  Rounds 0 and 1 are requested before the
@@ -588,33 +629,43 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       wait_landed(t, IntTag<4>{});
       __builtin_amdgcn_s_barrier();            // tile t visible; the stage of tile t-1 is no longer read
 #ifdef FCMF_GEMM_TIMING
-      if (t == 0) FCMF_STAMP(1);
-      if (t == 8) FCMF_STAMP(6);
+      if (t == 0) { FCMF_STAMP(1); stamp_cyc0 = __builtin_readcyclecounter(); }
+      if (t == 8 * 32 / KB) FCMF_STAMP(6);
 #endif
       issue_after_barrier(t);
       if constexpr (EARLY_AUX) {
         if (t == nkt - 1) { load_aux(0); load_aux(1); }
       }
-      load_frags(t);
-      mma();
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        load_frags(t, h);
+        mma();
+      }
     }
   } else {
     for (int t = 0; t < nkt; ++t) {
       wait_landed(t, IntTag<(MI == 8 ? 4 : 3)>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads of tile t-1 have left LDS
       __builtin_amdgcn_s_barrier();
-      if (t > 0) mma();                                     // tile t-1
+      if (t > 0) mma();                                     // last half of tile t-1
       issue_after_barrier(t);
-      load_frags(t);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        load_frags(t, h);
+        if (h + 1 < NH) mma();
+      }
     }
     if constexpr (EARLY_AUX) { load_aux(0); load_aux(1); }
-    mma();                                                  // last tile (nkt >= 1 always)
+    mma();                                                  // last half of the last tile (nkt >= 1 always)
   }
   if constexpr (HAS_AUX) {
 #pragma unroll
     for (int rnd = EARLY_AUX ? 2 : 0; rnd < (EARLY_AUX ? NRND : 2); ++rnd) load_aux(rnd);
   }
   FCMF_STAMP(2);
+#ifdef FCMF_GEMM_TIMING   // slot 7: shader-clock cycles of the main loop (s_memtime) -> the clock the loop ran at
+  if (blockIdx.x == 0 && threadIdx.x == 0 && g_stamp_buf && stamp_item < 16) g_stamp_buf[stamp_item * 8 + 7] = __builtin_readcyclecounter() - stamp_cyc0;
+#endif
   const int nbase = base + nkt;                 // ring position of the next item's tile 0
 
   TC* C = reinterpret_cast<TC*>(p.C);
@@ -655,10 +706,12 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         const Item wnx = decode(nxt);
         const Src snx = sources(wnx);
         issue(wnx, snx, 0, nbase);
-        if (1 < wnx.nkt) issue(wnx, snx, 1, nbase + 1);
+        if constexpr (KB == 32) {
+          if (1 < wnx.nkt) issue(wnx, snx, 1, nbase + 1);
 #ifndef FCMF_GEMM_DEPTH2
-        if (2 < wnx.nkt) issue(wnx, snx, 2, nbase + 2);
+          if (2 < wnx.nkt) issue(wnx, snx, 2, nbase + 2);
 #endif
+        }
       }
     }
     FCMF_STAMP(3);
@@ -1013,16 +1066,39 @@ static int launch_bf16(const GemmParams& p, int out_dtype, dim3 grid, hipStream_
 // inside a kernel template -- it would silently drop the host-side kernel handle)
 template <bool A_TR, bool B_TR, typename TC, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmParams p) {
-  gemm_bf16_tile256_body<A_TR, B_TR, TC, EPI, 8>(p);
+  gemm_bf16_tile256_body<A_TR, B_TR, TC, EPI, 8, 32>(p);
 }
 template <bool B_TR, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_tile192_kernel(GemmParams p) {
-  gemm_bf16_tile256_body<false, B_TR, bf16_t, EPI, 6>(p);
+  gemm_bf16_tile256_body<false, B_TR, bf16_t, EPI, 6, 32>(p);
+}
+// 64-deep k-tiles: both operands K-contiguous (every forward and dX GEMM of the bf16 step), bf16 output, K % 64 == 0
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tile256k64_kernel(GemmParams p) {
+  gemm_bf16_tile256_body<false, false, bf16_t, EPI, 8, 64>(p);
+}
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tile192k64_kernel(GemmParams p) {
+  gemm_bf16_tile256_body<false, false, bf16_t, EPI, 6, 64>(p);
 }
 
 template <bool A_TR, bool B_TR, typename TC, int EPI>
-static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, hipStream_t st, int tm) {
-  const size_t smem = (size_t)TNST * TSTAGE_BYTES + 8 * 4096;   // ring + per-wave transposition slices = 160 KiB
+static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, hipStream_t st, int tm, int kb) {
+  const size_t smem = (size_t)RING_BYTES + 8 * 4096;   // ring + per-wave transposition slices = 160 KiB
+  if constexpr (!A_TR && !B_TR && sizeof(TC) == 2) {
+    if (kb == 64) {
+      if (tm == 192) {
+        auto k = gemm_bf16_tile192k64_kernel<EPI>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+      } else {
+        auto k = gemm_bf16_tile256k64_kernel<EPI>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+      }
+      return;
+    }
+  }
   if constexpr (!A_TR && sizeof(TC) == 2) {
     if (tm == 192) {
       auto k = gemm_bf16_tile192_kernel<B_TR, EPI>;
@@ -1037,13 +1113,13 @@ static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, hipStream_t s
 }
 
 template <bool A_TR, bool B_TR>
-static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st, int tm) {
-  if (out_dtype == FCMF_F32) launch_bf16_tile_typed<A_TR, B_TR, float, FCMF_EPI_NONE>(p, grid, st, 256);
+static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipStream_t st, int tm, int kb) {
+  if (out_dtype == FCMF_F32) launch_bf16_tile_typed<A_TR, B_TR, float, FCMF_EPI_NONE>(p, grid, st, 256, 32);
   else switch (p.epilogue) {
-    case FCMF_EPI_NONE: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_NONE>(p, grid, st, tm); break;
-    case FCMF_EPI_GELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_GELU>(p, grid, st, tm); break;
-    case FCMF_EPI_DGELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_DGELU>(p, grid, st, tm); break;
-    default: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_ADD>(p, grid, st, tm); break;
+    case FCMF_EPI_NONE: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_NONE>(p, grid, st, tm, kb); break;
+    case FCMF_EPI_GELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_GELU>(p, grid, st, tm, kb); break;
+    case FCMF_EPI_DGELU: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_DGELU>(p, grid, st, tm, kb); break;
+    default: launch_bf16_tile_typed<A_TR, B_TR, bf16_t, FCMF_EPI_ADD>(p, grid, st, tm, kb); break;
   }
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
@@ -1096,6 +1172,8 @@ static thread_local char g_last_kernel[96] = "";
 extern "C" const char* fcmf_gemm_last_kernel(void) { return g_last_kernel; }
 static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced kernel (benchmarks, tests)
 extern "C" void fcmf_gemm_force_tile(int tile) { g_force_tile = tile; }
+// FCMF_GEMM_KB=32 (read once) keeps the 32-deep k-tiles everywhere (A/B measurements of the 64-deep variant)
+static int g_kb64 = [] { const char* e = getenv("FCMF_GEMM_KB"); return !(e && atoi(e) == 32); }();
 
 extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum, int M,
                          int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
@@ -1151,6 +1229,9 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       }
       if (g_force_tile == 192 && !trans_a && out_dtype == FCMF_BF16 && !accumulate) tm = 192;
       const int tiles_l = ((M + tm - 1) / tm) * ((N + GB - 1) / GB);
+      // 64-deep k-tiles where both operands are K-contiguous (whole-line DMA), the output is bf16 and K allows it
+      const int kb = (g_kb64 && !trans_a && !trans_b && out_dtype == FCMF_BF16 && !accumulate && K % 64 == 0) ? 64 : 32;
+      const int nk = (K + kb - 1) / kb;      // (shadows the 32-deep count above: the kernel counts k-tiles of ITS depth)
       int ksplit = 1;
       if (accumulate && epilogue == FCMF_EPI_NONE && tiles_l < slots) {
         ksplit = slots / tiles_l;
@@ -1171,14 +1252,15 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       }
       {
         static const char* const epi_names[] = {"NONE", "GELU", "TANH", "DGELU", "DTANH", "ADD"};
-        if (tm == 192) snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile192_kernel<%d,%s>", trans_b, epi_names[epilogue]);
+        if (kb == 64) snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile%dk64_kernel<%s>", tm, epi_names[epilogue]);
+        else if (tm == 192) snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile192_kernel<%d,%s>", trans_b, epi_names[epilogue]);
         else snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile256_kernel<%d,%d,%s,%s>", trans_a, trans_b, out_dtype == FCMF_F32 ? "f32" : "bf16", epi_names[epilogue]);
       }
       int rc;
-      if (!trans_a && !trans_b) rc = launch_bf16_tile<false, false>(p, out_dtype, grid, st, tm);
-      else if (!trans_a && trans_b) rc = launch_bf16_tile<false, true>(p, out_dtype, grid, st, tm);
-      else if (trans_a && !trans_b) rc = launch_bf16_tile<true, false>(p, out_dtype, grid, st, tm);
-      else rc = launch_bf16_tile<true, true>(p, out_dtype, grid, st, tm);
+      if (!trans_a && !trans_b) rc = launch_bf16_tile<false, false>(p, out_dtype, grid, st, tm, kb);
+      else if (!trans_a && trans_b) rc = launch_bf16_tile<false, true>(p, out_dtype, grid, st, tm, kb);
+      else if (trans_a && !trans_b) rc = launch_bf16_tile<true, false>(p, out_dtype, grid, st, tm, kb);
+      else rc = launch_bf16_tile<true, true>(p, out_dtype, grid, st, tm, kb);
       if (rc == FCMF_OK && p.ws) {
         const int64_t total4 = (int64_t)M * N / 4;
         const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);

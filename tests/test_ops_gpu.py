@@ -45,9 +45,10 @@ def test_gemm_layouts(dev, dtype, ta, tb, M, N, K):
 
 @pytest.mark.parametrize("tile", [128, 256, 192])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(700, 520, 96), (256, 256, 32), (1000, 776, 224)])
+@pytest.mark.parametrize("M,N,K", [(700, 520, 96), (256, 256, 32), (1000, 776, 224), (700, 520, 128), (1000, 776, 320)])
 def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
-    """all MFMA tile kernels (128x128, persistent 256x256 / 192x256 ping-pong) on ragged M/N edges and odd k-tile counts"""
+    """all MFMA tile kernels (128x128, persistent 256x256 / 192x256 ping-pong) on ragged M/N edges and odd k-tile counts;
+    K % 64 == 0 with both operands K-contiguous runs the 64-deep k-tile variant (2-stage ring, whole-line DMA)"""
     ops, H = _ops()
     A = _rand((K, M) if ta else (M, K), dev, torch.bfloat16, seed=1)
     B = _rand((K, N) if tb else (N, K), dev, torch.bfloat16, seed=2)
@@ -67,7 +68,9 @@ def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,nk_note", [(700, 520, 96, "3 k-tiles"), (4400, 4104, 64, "306 tiles: two rounds of work items per CU"),
-                                           (300, 264, 32, "1 k-tile"), (1100, 776, 160, "5 k-tiles")])
+                                           (300, 264, 32, "1 k-tile"), (1100, 776, 160, "5 k-tiles"),
+                                           (1100, 776, 192, "3 k-tiles of 64"), (4400, 4104, 128, "2 k-tiles of 64, two rounds"),
+                                           (49152 // 8, 768, 768, "12 k-tiles of 64: a slice of the step's own shape")])
 @pytest.mark.parametrize("tile", [256, 192])
 def test_gemm_tile256_epilogues(dev, tile, M, N, K, nk_note):
     """persistent 256x256 / 192x256 kernels, bf16 outputs: every fused epilogue kind (bias / GELU + aux / gelu' / residual

@@ -42,6 +42,12 @@ int main(int argc, char** argv) {
       {"dW   768x3072  TN k=49152", 768, 3072, T, 1, 1, FCMF_EPI_NONE, 1, 1},
       {"fwd  vismap    NT 21952x768x2048", 21952, 768, 2048, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"sq   NT 4096^3", 4096, 4096, 4096, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"sq   NN 4096^3", 4096, 4096, 4096, 0, 1, FCMF_EPI_NONE, 0, 0},
+      {"sq   TN 4096^3 bf16 out", 4096, 4096, 4096, 1, 1, FCMF_EPI_NONE, 0, 0},
+      {"sq   TN 4096^3 f32 acc", 4096, 4096, 4096, 1, 1, FCMF_EPI_NONE, 1, 1},
+      {"sq   TT 4096^3 (A^T, B [N,K])", 4096, 4096, 4096, 1, 0, FCMF_EPI_NONE, 0, 0},
+      {"sq   NT 8192^3", 8192, 8192, 8192, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"sq   TN 8192^3 bf16 out", 8192, 8192, 8192, 1, 1, FCMF_EPI_NONE, 0, 0},
 
       {"small NT 2048x768x768", 2048, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"small NT 2048x3072x768", 2048, 3072, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
@@ -59,7 +65,7 @@ int main(int argc, char** argv) {
       {"scan NT 5376x3072 K=768 (252 tiles)", 5376, 3072, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"scan NT 5376x3072 K=3072 (252 tiles)", 5376, 3072, 3072, 0, 0, FCMF_EPI_NONE, 0, 0},
   };
-  size_t maxA = (size_t)T * 3072, maxB = (size_t)T * 3072, maxC = (size_t)T * 3072;
+  size_t maxA = (size_t)T * 3072, maxB = (size_t)T * 3072, maxC = (size_t)T * 3072;   // >= 8192^2 too
   unsigned short *A, *B; void *C, *AUX; float* bias;
   hipMalloc(&A, maxA * 2); hipMalloc(&B, maxB * 2); hipMalloc(&C, maxC * 4); hipMalloc(&AUX, maxC * 2); hipMalloc(&bias, 4096 * 4);
   {
@@ -82,7 +88,9 @@ int main(int argc, char** argv) {
   hipStream_t hs; hipStreamCreate(&hs);
   if (hog) hipFuncSetAttribute((const void*)hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const char* only = argc > 3 ? argv[3] : nullptr;   // run only the shapes whose name starts with this
   for (auto& sh : shapes) {
+    if (only && strncmp(sh.name, only, strlen(only)) != 0) continue;
     int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.N : sh.K, ldc = sh.N;
     auto run = [&]() {
       return fcmf_gemm(A, B, C, sh.acc ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU || sh.epi == FCMF_EPI_ADD) ? AUX : nullptr, nullptr,
@@ -120,7 +128,8 @@ int main(int argc, char** argv) {
       printf("    item: fill  loop(8kt..end)  ->barrier  finish  stores | total   [us, 100 MHz stamps, workgroup 0 wave 0]\n");
       for (int it = 0; it < 10 && h[it * 8 + 5]; ++it) {
         auto d = [&](int a, int b2) { return (double)(long long)(h[it * 8 + b2] - h[it * 8 + a]) * 0.01; };
-        printf("    %4d: %5.2f %5.2f+%5.2f %5.2f %5.2f %5.2f | %6.2f\n", it, d(0, 1), d(1, 6), d(6, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 5));
+        printf("    %4d: %5.2f %5.2f+%5.2f %5.2f %5.2f %5.2f | %6.2f   loop clock %.0f MHz (s_memtime / s_memrealtime)\n", it, d(0, 1), d(1, 6), d(6, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 5),
+               (double)h[it * 8 + 7] / d(1, 2));
       }
     }
   }
