@@ -397,7 +397,8 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   constexpr int WM = 16 * MI;                  // rows per wave
   constexpr int A_TILE_BYTES = GB * KB * 2;    // LDS bytes per operand tile (the 192-row A tile leaves a quarter unused)
   constexpr int TSTAGE_BYTES = 2 * A_TILE_BYTES;
-  constexpr int TNST = RING_BYTES / TSTAGE_BYTES;   // 4 or 2
+  constexpr int TNST = 4;                      // KB = 32: stages of the ring (A tile + B tile each)
+  constexpr bool RING5 = KB == 64;             // KB = 64: five 32-KiB slots, one OPERAND tile each (see `base` below)
   constexpr int NH = KB / 32;                  // 32-deep halves of a k-tile (MFMA k = 32)
   constexpr int A_PIECES = KB / 16, B_PIECES = KB / 16;   // 1 KiB DMA pieces per wave per operand tile (A: see na_pieces)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -433,7 +434,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   const int trk = tr_key(8 * g4 + q4);
   const int tr_col = ((p4 >> 1) << 4) + ((p4 & 1) << 3);
   const int a_lane = A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * WM * (2 * KB);
-  const int b_lane = A_TILE_BYTES + (B_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wn * 64 * (2 * KB));
+  const int b_lane = B_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wn * 64 * (2 * KB);
   auto frag_a = [&](const char* st, int f, int h) -> bf16x8 {     // f = 0..MI-1: 16-row fragment of this wave's rows
     if (!A_TR) return *reinterpret_cast<const bf16x8*>(st + (a_lane ^ (h << 6)) + f * (32 * KB));
     const char* q = st + a_lane + (((wm * 8 + f) ^ trk) << 5) + h * 16384;
@@ -460,9 +461,22 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     const int kb = zsplit * p.ktiles_per_split;
     return Item{tile_m * TM, tile_n * GB, kb, min(nk_total, kb + p.ktiles_per_split) - kb, zsplit};
   };
-  // ring: k-tile t of the current item lives in stage (base + t) % 4; `base` runs on across items
-  int base = 0;
-  auto stage_at = [&](int s) { return smem + (s & (TNST - 1)) * TSTAGE_BYTES; };
+  // KB = 32 ring: k-tile t of the current item lives in stage (base + t) % 4 (A tile, then B tile); `base` runs on across
+  // items.  Three k-tiles in flight.
+  // KB = 64 ring: the whole 160 KiB as five slots of one operand tile; with n = 2t for A_t and n = 2t + 1 for B_t, tile n
+  // lives in slot (base + n) % 5.  While tile t is multiplied, A_{t+1} (issued one barrier earlier), B_{t+1} and A_{t+2}
+  // are in flight: the DMA stream never drains at a barrier, which a 2 x 64 KiB double buffer (one whole k-tile issued
+  // and awaited per barrier interval: latency-bound) cannot offer.  The bf16 epilogue's transposition slices take the
+  // slot of the NEXT item's A_1, which is therefore issued after that item's first barrier.
+  int base = 0;                              // KB = 32: stage of the current item's tile 0; KB = 64: slot of A_t (runs with t)
+  auto stage_at = [&](int rel) -> char* {    // KB = 32; rel = k-tile index relative to the current item's tile 0 (may run into the next item)
+    return smem + ((base + rel) & (TNST - 1)) * TSTAGE_BYTES;
+  };
+  auto slot_at = [&](int d) -> char* {       // KB = 64: the slot d (0..4) positions after that of the current A tile
+    int x = base + d;
+    x = x >= 5 ? x - 5 : x;
+    return smem + x * 32768;
+  };
   // per-lane DMA source offsets of an item's operand tiles (k-tile 0): computed ONCE per item
   struct Src { unsigned a[A_PIECES], b[B_PIECES]; };
   auto sources = [&](const Item& w) -> Src {
@@ -478,12 +492,11 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR, KB>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
     return r;
   };
-  // DMA of k-tile t of item w into ring stage s
-  auto issue = [&](const Item& w, const Src& src, int t, int s) {
+  // DMA of k-tile t of item w: A tile to sa and / or B tile to sb (nullptr = skip)
+  auto issue_ab = [&](const Item& w, const Src& src, int t, char* sa, char* sb) {
 #ifdef FCMF_GEMM_ABLATE_DMA      // diagnostic build: no global->LDS traffic (the ring holds whatever it held)
     return;
 #endif
-    char* st = stage_at(s);
 #ifdef FCMF_GEMM_ABLATE_SRC      // diagnostic build: every DMA piece re-reads the SAME first 1 KiB of its operand (L1 hits)
     const unsigned ka = 0, kb = 0;
 #else
@@ -495,19 +508,27 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
 #endif
 #endif
+    if (sa) {
 #pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) {
-      if (MI != 8 && j >= na_pieces) break;
-      char* d = st + (a_piece0 + j) * 1024;
-      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j] + ka, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j], ka, 0, 0);
+      for (int j = 0; j < A_PIECES; ++j) {
+        if (MI != 8 && j >= na_pieces) break;
+        char* d = sa + (a_piece0 + j) * 1024;
+        if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j] + ka, 0, 0, 0);
+        else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j], ka, 0, 0);
+      }
     }
+    if (sb) {
 #pragma unroll
-    for (int j = 0; j < B_PIECES; ++j) {
-      char* d = st + A_TILE_BYTES + (wave * B_PIECES + j) * 1024;
-      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, src.b[j] + kb, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, src.b[j], kb, 0, 0);
+      for (int j = 0; j < B_PIECES; ++j) {
+        char* d = sb + (wave * B_PIECES + j) * 1024;
+        if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, src.b[j] + kb, 0, 0, 0);
+        else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, src.b[j], kb, 0, 0);
+      }
     }
+  };
+  auto issue = [&](const Item& w, const Src& src, int t, int rel) {     // KB = 32: both tiles of k-tile t into stage `rel`
+    char* st = stage_at(rel);
+    issue_ab(w, src, t, st, st + A_TILE_BYTES);
   };
   auto lds_barrier = [&]() {   // LDS traffic of this wave retired, then the workgroup barrier; global stores stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -529,11 +550,18 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   // after barrier t.  Own DMAs of tile t have landed once at most the two younger tiles (4 DMAs each) are
   // outstanding: loads retire in order, and stores of the previous epilogue that are still in flight only
   // make the wait longer.
-  // (KB = 64: ONE k-tile in flight -- tile t + 1 is issued after barrier t and has landed at vmcnt(0).)
+  // KB = 64 (five operand slots): A_0, B_0 before the loop (or from the previous epilogue); after every barrier t:
+  // B_{t+1}, then the A tiles up to A_{t+2} that are not yet in flight (A_1 and A_2 after barrier 0, one afterwards).
+  // Before barrier t only A_{t+1} (this wave's youngest DMAs), if already issued, may be outstanding.
+  [[maybe_unused]] int a_next = 1;            // first A tile of this item that has not been issued
   auto wait_landed = [&](int t, auto per_tile) {
     constexpr int PT = decltype(per_tile)::value;   // DMAs per k-tile of this wave: 4, or 3 for waves 4-7 of the 192-row tile
     const int younger = nkt - 1 - t;
-    if constexpr (KB == 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    if constexpr (RING5) {
+      if (a_next > t + 1) { if (MI == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
 #ifdef FCMF_GEMM_DEPTH2        // diagnostic build: two k-tiles in flight instead of three (prefetch-depth sensitivity)
     if (younger >= 1) { if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -544,12 +572,18 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto issue_after_barrier = [&](int t) {
-    if constexpr (KB == 64) { if (t + 1 < nkt) issue(w, src, t + 1, base + t + 1); return; }
+    if constexpr (RING5) {
+      if (t + 1 < nkt) issue_ab(w, src, t + 1, nullptr, slot_at(3));
+      const int a_end = min(nkt, t + 3);
+      for (; a_next < a_end; ++a_next)         // (two trips after barrier 0, one afterwards)
+        issue_ab(w, src, a_next, slot_at(2 * (a_next - t)), nullptr);
+      return;
+    }
 #ifdef FCMF_GEMM_DEPTH2
-    if (t + 2 < nkt) issue(w, src, t + 2, base + t + 2);
+    if (t + 2 < nkt) issue(w, src, t + 2, t + 2);
     return;
 #endif
-    if (t + 3 < nkt) issue(w, src, t + 3, base + t + 3);
+    if (t + 3 < nkt) issue(w, src, t + 3, t + 3);
   };
 
   f32x4 acc[4][MI];  // [j frag][i frag]
@@ -566,11 +600,12 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 #ifdef FCMF_GEMM_ABLATE_FRAGS    // diagnostic build (with ABLATE_MMA): no fragment reads either -> the DMA stream alone
     return;
 #endif
-    const char* st = stage_at(base + t);
+    const char* sa = RING5 ? slot_at(0) : stage_at(t);
+    const char* sb = RING5 ? slot_at(1) : stage_at(t) + A_TILE_BYTES;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) fb[f] = frag_b(st, f, h);
+    for (int f = 0; f < 4; ++f) fb[f] = frag_b(sb, f, h);
 #pragma unroll
-    for (int f = 0; f < MI; ++f) fa[f] = frag_a(st, f, h);
+    for (int f = 0; f < MI; ++f) fa[f] = frag_a(sa, f, h);
   };
   auto mma = [&]() {
 #ifdef FCMF_GEMM_ABLATE_MMA      // diagnostic build: feed only (fragments stay live, no matrix instructions)
@@ -589,11 +624,12 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   };
 
   if (!pre) {
-    issue(w, src, 0, base);
+    if constexpr (RING5) issue_ab(w, src, 0, slot_at(0), slot_at(1));
+    else issue(w, src, 0, 0);
     if constexpr (KB == 32) {
-      if (1 < nkt) issue(w, src, 1, base + 1);
+      if (1 < nkt) issue(w, src, 1, 1);
 #ifndef FCMF_GEMM_DEPTH2
-      if (2 < nkt) issue(w, src, 2, base + 2);
+      if (2 < nkt) issue(w, src, 2, 2);
 #endif
     }
   }
@@ -641,6 +677,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         load_frags(t, h);
         mma();
       }
+      if constexpr (RING5) { base += 2; base = base >= 5 ? base - 5 : base; }
     }
   } else {
     for (int t = 0; t < nkt; ++t) {
@@ -654,6 +691,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         load_frags(t, h);
         if (h + 1 < NH) mma();
       }
+      if constexpr (RING5) { base += 2; base = base >= 5 ? base - 5 : base; }
     }
     if constexpr (EARLY_AUX) { load_aux(0); load_aux(1); }
     mma();                                                  // last half of the last tile (nkt >= 1 always)
@@ -666,13 +704,12 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 #ifdef FCMF_GEMM_TIMING   // slot 7: shader-clock cycles of the main loop (s_memtime) -> the clock the loop ran at
   if (blockIdx.x == 0 && threadIdx.x == 0 && g_stamp_buf && stamp_item < 16) g_stamp_buf[stamp_item * 8 + 7] = __builtin_readcyclecounter() - stamp_cyc0;
 #endif
-  const int nbase = base + nkt;                 // ring position of the next item's tile 0
 
   TC* C = reinterpret_cast<TC*>(p.C);
   if constexpr (sizeof(TC) == 2) {
     // ---- wave-local bf16 epilogue ------------------------------------------------------------------
     // Every wave of the workgroup has passed barrier nkt-1, so every stage except that of tile nkt-1
-    // (= nbase + 3) is drained: nbase + 0 / 1 / 2 take the next item's tiles 0 / 1 / 2 now (tile 3 follows
+    // is drained: the positions nkt + 0 / 1 / 2 take the next item's tiles 0 / 1 / 2 now (tile 3 follows
     // after ITS barrier 0, the regular schedule).  The 32 KiB above the ring hold a private 4 KiB
     // transposition slice per wave ([32 rows][64 columns] bf16, 16-B chunk ^ ((row >> 1) & 7): conflict-free
     // both ways), so the epilogue never touches the ring.
@@ -683,7 +720,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     const unsigned tile_off = (unsigned)(i0 + wm * WM) * ldc2 + (unsigned)(j0 + wn * 64) * 2u;   // wave's sub-tile
     // transposition slice: fragment-layout accesses are 8 B per lane, row-layout accesses 16 B per lane (whole
     // 128-B row pieces, 8 rows per instruction); LDS executes a wave's accesses in order
-    char* slice = smem + TNST * TSTAGE_BYTES + wave * 4096;
+    char* slice = (RING5 ? slot_at(2) : smem + RING_BYTES) + wave * 4096;   // (KB = 64: `base` is the next item's A_0 slot by now; its A_1 slot)
     char* wbase = slice + er * 128 + (eg & 1) * 8;
     auto frag_addr = [&](int h, int fj) __attribute__((always_inline)) -> char* {   // fragment (row block h of the round, fj)
       const int row = h * 16 + er, chunk = fj * 2 + (eg >> 1);
@@ -705,11 +742,12 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       if (pre) {
         const Item wnx = decode(nxt);
         const Src snx = sources(wnx);
-        issue(wnx, snx, 0, nbase);
+        if constexpr (RING5) issue_ab(wnx, snx, 0, slot_at(0), slot_at(1));
+        else issue(wnx, snx, 0, nkt);
         if constexpr (KB == 32) {
-          if (1 < wnx.nkt) issue(wnx, snx, 1, nbase + 1);
+          if (1 < wnx.nkt) issue(wnx, snx, 1, nkt + 1);
 #ifndef FCMF_GEMM_DEPTH2
-          if (2 < wnx.nkt) issue(wnx, snx, 2, nbase + 2);
+          if (2 < wnx.nkt) issue(wnx, snx, 2, nkt + 2);
 #endif
         }
       }
@@ -913,7 +951,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       lds_barrier();
     }
   }
-  base = nbase & (TNST - 1);
+  if constexpr (!RING5) base = (base + nkt) & (TNST - 1);
   FCMF_STAMP(5);
   }  // work items
 }
@@ -1230,12 +1268,13 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       if (g_force_tile == 192 && !trans_a && out_dtype == FCMF_BF16 && !accumulate) tm = 192;
       const int tiles_l = ((M + tm - 1) / tm) * ((N + GB - 1) / GB);
       // 64-deep k-tiles where both operands are K-contiguous (whole-line DMA), the output is bf16 and K allows it
+      // (weight gradients -- token-major operands, 512-B DMA rows already -- measured 4-8 % SLOWER on 64-deep k-tiles)
       const int kb = (g_kb64 && !trans_a && !trans_b && out_dtype == FCMF_BF16 && !accumulate && K % 64 == 0) ? 64 : 32;
       const int nk = (K + kb - 1) / kb;      // (shadows the 32-deep count above: the kernel counts k-tiles of ITS depth)
       int ksplit = 1;
       if (accumulate && epilogue == FCMF_EPI_NONE && tiles_l < slots) {
         ksplit = slots / tiles_l;
-        const int min_kt = nk >= 64 ? 8 : 6;      // k-tiles per work item: short contractions (K = 768 rows) split 4 ways
+        const int min_kt = (nk * (kb / 32) >= 64 ? 8 : 6) / (kb / 32);   // >= 256 (192) k per work item: short contractions (K = 768 rows) split 4 ways
         if (ksplit > nk / min_kt) ksplit = nk / min_kt > 0 ? nk / min_kt : 1;
         if (ksplit > 64) ksplit = 64;
       }

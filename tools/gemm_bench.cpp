@@ -32,11 +32,13 @@ int main(int argc, char** argv) {
       {"fwd  ffn1+gelu NT 49152x3072x768", T, 3072, 768, 0, 0, FCMF_EPI_GELU, 0, 0},
       {"fwd  ffn1 noepi NT 49152x3072x768", T, 3072, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"fwd  ffn2      NT 49152x768x3072", T, 768, 3072, 0, 0, FCMF_EPI_NONE, 0, 0},
-      {"dX   out       NN 49152x768x768", T, 768, 768, 0, 1, FCMF_EPI_NONE, 0, 0},
-      {"dX   ffn2+dgelu NN 49152x3072x768", T, 3072, 768, 0, 1, FCMF_EPI_DGELU, 0, 0},
-      {"dX   ffn1      NN 49152x768x3072", T, 768, 3072, 0, 1, FCMF_EPI_NONE, 0, 0},
-      {"dX   qkv       NN 49152x768x2304", T, 768, 2304, 0, 1, FCMF_EPI_NONE, 0, 0},
-      {"dX   qkv+add   NN 49152x768x2304", T, 768, 2304, 0, 1, FCMF_EPI_ADD, 0, 0},
+      // (the bf16 step multiplies dY by the TRANSPOSED bf16 shadow of W: dX GEMMs are NT like the forward ones)
+      {"dX   out       NT 49152x768x768", T, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"dX   ffn2+dgelu NT 49152x3072x768", T, 3072, 768, 0, 0, FCMF_EPI_DGELU, 0, 0},
+      {"dX   ffn1      NT 49152x768x3072", T, 768, 3072, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"dX   qkv       NT 49152x768x2304", T, 768, 2304, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"dX   qkv+add   NT 49152x768x2304", T, 768, 2304, 0, 0, FCMF_EPI_ADD, 0, 0},
+      {"f32-mode dX ffn1 NN 49152x768x3072", T, 768, 3072, 0, 1, FCMF_EPI_NONE, 0, 0},
       {"dW   768x768   TN k=49152", 768, 768, T, 1, 1, FCMF_EPI_NONE, 1, 1},
       {"dW   3072x768  TN k=49152", 3072, 768, T, 1, 1, FCMF_EPI_NONE, 1, 1},
       {"dW   768x3072  TN k=49152", 768, 3072, T, 1, 1, FCMF_EPI_NONE, 1, 1},
