@@ -134,7 +134,10 @@ int fcmf_attn_mfma_bwd(const void* q, const void* k, const void* v, const float*
                        const void* out, const void* dout, const float* lse,
                        void* dq, void* dk, void* dv, int G, int heads, int Tq, int Tk,
                        int64_t ldq, int64_t ldk, int64_t ldo, float scale,
-                       float dropout_p, uint64_t seed, void* stream);
+                       float dropout_p, uint64_t seed, float* colsum, void* stream);
+/* colsum (may be NULL): float32 [G][3*heads*64]; row g receives the column sums of sequence g's dq | dk | dv (taken from
+ * the f32 accumulators).  Their sum over g is the bias gradient of a fused q|k|v projection (the autograd of
+ * mm_modeling.py:182-184 / HF RobertaSelfAttention's three nn.Linear biases) without another pass over dqkv. */
 
 /* ---------------------------------------------------------------------------------------
  * y = LayerNorm(dropout(x) + res) * gamma + beta   (eps inside the sqrt, biased variance)

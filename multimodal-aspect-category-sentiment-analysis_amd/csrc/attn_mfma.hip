@@ -125,6 +125,7 @@ struct AttnMfmaParams {
   const float* mask;
   bf16_t *out, *dq, *dk, *dv;
   float* lse;
+  float* colsum;       // backward, optional: [G][3 * heads * 64] f32, row g = column sums of dq | dk | dv of sequence g
   int G, heads, Tq, Tk;
   int64_t ldq, ldk, ldo;
   float scale, p;
@@ -434,6 +435,7 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
   // [key][q] of (chunk, query tile) in LDS, phase 2 adds them to dQ of that tile (wave = 32 queries) and to dV / dK of
   // the chunk's 32 keys (wave = 16 columns), which are stored after the last query tile
   const int nchunks = (P.Tk + 31) >> 5;
+  f32x4 cV = f32x4{0.f, 0.f, 0.f, 0.f}, cK = f32x4{0.f, 0.f, 0.f, 0.f};   // column sums of dV / dK over the keys (this lane's keys)
   for (int c = 0; c < nchunks; ++c) {
     f32x4 aV[2], aK[2];
 #pragma unroll
@@ -505,6 +507,8 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
       __syncthreads();   // the chunk images are rewritten by the next query tile / chunk
     }
     const int dcol = h * AD + 16 * w + 4 * (lane >> 4);
+    cV += aV[0] + aV[1];        // (keys past Tk carry zero probabilities: no mask needed)
+    cK += aK[0] + aK[1];
 #pragma unroll
     for (int kf = 0; kf < 2; ++kf) {
       const int key = 32 * c + 16 * kf + (lane & 15);
@@ -531,6 +535,41 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
         }
       }
     }
+  // ---- optional: column sums of this (sequence, head)'s dq | dk | dv (f32 accumulators, before the bf16 rounding): the
+  // bias gradient of the fused q|k|v projection is their sum over the sequences -- saves a pass over dqkv
+  if (P.colsum) {
+    const int HD = P.heads * AD;
+    float* row = P.colsum + (int64_t)g * 3 * HD + h * AD;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { cV[r] += __shfl_xor(cV[r], o, 64); cK[r] += __shfl_xor(cK[r], o, 64); }
+    if ((lane & 15) == 0) {      // d = 16 w + 4 (lane >> 4) + r: the workgroup owns these 64 columns of row g
+      const int d0 = 16 * w + 4 * (lane >> 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { row[2 * HD + d0 + r] = cV[r]; row[HD + d0 + r] = cK[r] * P.scale; }
+    }
+    // dq: rows q = .. + (lane & 15) over the fragments, query tiles and the four waves (through LDS; PdT is free now)
+    float* red = reinterpret_cast<float*>(PdT);    // [4 waves][64 d]
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) t += aQ[qt][df][f];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) t[r] += __shfl_xor(t[r], o, 64);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w * 64 + 16 * df + 4 * (lane >> 4) + r] = t[r];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) row[tid] = (red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]) * P.scale;
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(AttnMfmaParams P) { attn_mfma_bwd_body<1, 1>(P); }
@@ -578,7 +617,7 @@ extern "C" int fcmf_attn_mfma_fwd(const void* q, const void* k, const void* v, c
 extern "C" int fcmf_attn_mfma_bwd(const void* q, const void* k, const void* v, const float* mask, const void* out,
                                   const void* dout, const float* lse, void* dq, void* dk, void* dv, int G, int heads,
                                   int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldo, float scale, float dropout_p,
-                                  uint64_t seed, void* stream) {
+                                  uint64_t seed, float* colsum, void* stream) {
   if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || G <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0) return FCMF_ERR_ARG;
   if (Tk > 2 * AT || Tq > 2 * AT || ldq % 8 || ldk % 8 || ldo % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(out) || !al16(dout) ||
       !al16(dq) || !al16(dk) || !al16(dv))
@@ -587,7 +626,7 @@ extern "C" int fcmf_attn_mfma_bwd(const void* q, const void* k, const void* v, c
   P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.mask = mask; P.o = (const bf16_t*)out;
   P.dout = (const bf16_t*)dout; P.lse = const_cast<float*>(lse); P.dq = (bf16_t*)dq; P.dk = (bf16_t*)dk; P.dv = (bf16_t*)dv;
   P.G = G; P.heads = heads; P.Tq = Tq; P.Tk = Tk; P.ldq = ldq; P.ldk = ldk; P.ldo = ldo;
-  P.scale = scale; P.p = dropout_p; P.seed = seed;
+  P.scale = scale; P.p = dropout_p; P.seed = seed; P.colsum = colsum;
   if (Tk > AT || Tq > AT) {
     const int smem = 9 * TILE_B;   // 2 x (Q, dO) + 2 x (K, V) tiles + the two 8 KiB chunk images = 144 KiB: one workgroup per CU
     static bool attr2 = false;

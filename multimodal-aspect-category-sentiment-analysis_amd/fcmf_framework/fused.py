@@ -146,15 +146,20 @@ def self_attention_fwd(qkv, mask, G, T, Hd, heads, p, seed):
     return out, lse
 
 
-def self_attention_bwd(qkv, mask, out, lse, dout, G, T, Hd, heads, p, seed):
+def self_attention_bwd(qkv, mask, out, lse, dout, G, T, Hd, heads, p, seed, bias_grad=None):
+    """-> dqkv [G*T, 3H].  bias_grad (float32 [3H], accumulated into): the column sums of dqkv = the gradient of the fused
+    q|k|v bias; the MFMA kernel produces them per sequence from its f32 accumulators (no extra pass over dqkv)."""
     scale = 1.0 / math.sqrt(Hd // heads)
     es, base, L = qkv.element_size(), qkv.data_ptr(), H.lib()
     if _use_mfma(qkv.dtype, Hd, heads, T):
         dqkv = torch.empty_like(qkv)
         db = dqkv.data_ptr()
+        part = None if bias_grad is None else torch.empty((G, 3 * Hd), dtype=torch.float32, device=qkv.device)
         H.check(L.fcmf_attn_mfma_bwd(base, base + Hd * es, base + 2 * Hd * es, H.ptr(mask), H.ptr(out), H.ptr(dout), H.ptr(lse),
                                      db, db + Hd * es, db + 2 * Hd * es, G, heads, T, T, 3 * Hd, 3 * Hd, Hd, scale, p, seed,
-                                     H.stream()), "fcmf_attn_mfma_bwd")
+                                     H.ptr(part), H.stream()), "fcmf_attn_mfma_bwd")
+        if part is not None:
+            H.check(L.fcmf_colsum(H.ptr(part), H.ptr(bias_grad), G, 3 * Hd, 3 * Hd, H.dt(part), 1, H.stream()), "fcmf_colsum")
         return dqkv
     a = _qkv_desc(qkv, G, T, Hd, heads, mask, scale, p, seed)
     nch = max(1, (T + 127) // 128)
@@ -163,7 +168,10 @@ def self_attention_bwd(qkv, mask, out, lse, dout, G, T, Hd, heads, p, seed):
     dv = torch.empty((G, T, Hd), dtype=qkv.dtype, device=qkv.device)
     H.check(L.fcmf_attn_small_bwd(a, H.ptr(out), H.ptr(dout), H.ptr(lse), H.ptr(dq), H.ptr(dk), H.ptr(dv), 0, 0, 0, H.stream()),
             "fcmf_attn_small_bwd")
-    return torch.cat((ops._sum_leading(dq), dk, dv), dim=-1).view(G * T, 3 * Hd)
+    dqkv = torch.cat((ops._sum_leading(dq), dk, dv), dim=-1).view(G * T, 3 * Hd)
+    if bias_grad is not None:
+        H.check(L.fcmf_colsum(H.ptr(dqkv), H.ptr(bias_grad), G * T, 3 * Hd, 3 * Hd, H.dt(dqkv), 1, H.stream()), "fcmf_colsum")
+    return dqkv
 
 
 # --------------------------------------------------------------------------------------
@@ -323,13 +331,12 @@ class SelfLayerFn(torch.autograd.Function):
                              g2=g2, be2=be2))
         side = _SideGemms(x2.device)
         dc, dz1 = _post_bwd(dy.reshape(M, Hd).contiguous(), c, saved, wo, w1, w2, g1, g2, p_h, (s0, s1), G, side)
-        dqkv = self_attention_bwd(qkv, mk, c, lse, dc, G_, T, Hd, heads, p_a, seed_a)
+        dqkv = self_attention_bwd(qkv, mk, c, lse, dc, G_, T, Hd, heads, p_a, seed_a, bias_grad=G["bqkv"])
         wqkv = _fused_weight([wq, wk, wv], dt)
         dx = torch.empty((M, Hd), dtype=dt, device=x2.device)
         wm = _fused_weight([wq, wk, wv], torch.float32)
         ops.gemm_dx(dqkv, wm if wm.data_ptr() == wq.data_ptr() else None, wqkv, dx, M, Hd, 3 * Hd, aux=dz1, epi=H.EPI_ADD)   # + residual gradient
         side.launch((dqkv, x2), dqkv, x2, G["wqkv"], 3 * Hd, Hd, M, 3 * Hd, Hd, Hd, 1, 1, acc=True)
-        H.check(H.lib().fcmf_colsum(H.ptr(dqkv), H.ptr(G["bqkv"]), M, 3 * Hd, 3 * Hd, H.dt(dqkv), 1, H.stream()), "fcmf_colsum")
         side.join()
         W, b = G["wqkv"], G["bqkv"]
         return (dx.view(xshape), None, W[:Hd], b[:Hd], W[Hd:2 * Hd], b[Hd:2 * Hd], W[2 * Hd:], b[2 * Hd:], G["wo"], G["bo"],

@@ -816,7 +816,7 @@ class AttentionFn(torch.autograd.Function):
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k1), torch.empty_like(v1)
             H.check(H.lib().fcmf_attn_mfma_bwd(H.ptr(q), H.ptr(k1), H.ptr(v1), H.ptr(mask), H.ptr(out), H.ptr(dout),
                                                H.ptr(lse), H.ptr(dq), H.ptr(dk), H.ptr(dv), G, heads, R, k1.shape[1], HD, HD,
-                                               HD, scale, p, seed, H.stream()), "fcmf_attn_mfma_bwd")
+                                               HD, scale, p, seed, None, H.stream()), "fcmf_attn_mfma_bwd")
             return dq, dk, dv, None, None, None, None, None, None, None, None, None, None
         T1 = 0 if k1 is None else k1.shape[1]
         nch = max(1, (T1 + 127) // 128)

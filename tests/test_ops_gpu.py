@@ -663,6 +663,28 @@ def test_bertadam_matches_golden(dev):
 
 
 # ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T", [128, 77, 256, 130])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attention_mfma_backward_column_sums(dev, T, p):
+    """the fused q|k|v bias gradient: per-sequence column sums of dq | dk | dv out of the MFMA backward's f32
+    accumulators == column sums of the dqkv it stores (to bf16 rounding of the stored values)"""
+    from fcmf_framework import fused, ops
+    G, heads, d = 5, 3, 64
+    Hd = heads * d
+    qkv = _rand((G * T, 3 * Hd), dev, torch.bfloat16, 0.8, seed=1)
+    m01 = (torch.rand(G, T, generator=torch.Generator().manual_seed(7)) > 0.25).float()
+    m01[:, 0] = 1
+    mask = ((1 - m01) * torch.finfo(torch.float32).min).to(dev)
+    out, lse = fused.self_attention_fwd(qkv, mask, G, T, Hd, heads, p, 11)
+    dout = _rand((G * T, Hd), dev, torch.bfloat16, 1.0, seed=3)
+    bg = torch.full((3 * Hd,), 0.25, dtype=torch.float32, device=dev)        # accumulated into
+    dqkv = fused.self_attention_bwd(qkv, mask, out, lse, dout, G, T, Hd, heads, p, 11, bias_grad=bg)
+    dqkv2 = fused.self_attention_bwd(qkv, mask, out, lse, dout, G, T, Hd, heads, p, 11)
+    assert torch.equal(dqkv, dqkv2)
+    ref = dqkv.float().sum(0) + 0.25
+    assert (bg - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 1e-3
+
+
 @pytest.mark.parametrize("Tq,Tk", [(128, 128), (77, 128), (128, 50), (33, 17), (256, 256), (200, 256), (256, 150), (130, 129)])
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_attention_mfma_matches_reference_and_valu_kernel(dev, Tq, Tk, p):

@@ -1,4 +1,4 @@
-B=tools/bin/gemm_bench
-echo "## product"; $B 10 0 fwd; $B 10 0 dW
-echo "## prio_b"; LD_LIBRARY_PATH=tools/bin/prio_b $B 10 0 fwd; LD_LIBRARY_PATH=tools/bin/prio_b $B 10 0 dW
-echo "## product"; $B 10 0 fwd; $B 10 0 dW
+timeout -k 10 600 python -m pytest tests/test_ops_gpu.py tests/test_parity_gpu.py tests/test_abi.py -q -x > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
+tail -2 gpurun_out/t.log
+python bench.py --no-cpu-baseline > gpurun_out/b1.json 2>gpurun_out/b.err && python bench.py --no-cpu-baseline > gpurun_out/b2.json 2>>gpurun_out/b.err
+cut -c80-200 gpurun_out/b1.json gpurun_out/b2.json
