@@ -120,6 +120,14 @@ int fcmf_attn_small_fwd(const fcmf_attn_desc* desc /*host*/, void* out, float* l
 int fcmf_attn_small_bwd(const fcmf_attn_desc* desc /*host*/, const void* out, const void* dout,
                         const float* lse, void* dq, void* dk1, void* dv1, void* dk2, void* dv2,
                         float* dbias, void* stream);
+/* The same backward where the `group_div` consecutive groups that share private keys (the six aspects of a review:
+ * fcmf_multimodal.py:84-124 under aspect batching) also share their gradients: dk2 / dv2 are
+ * [G/group_div, R, T2, heads*d], already summed over the group.  scratch: caller-owned device memory,
+ * >= 2*G*heads*R*T2*4 bytes (the private keys' probabilities and score gradients between the two kernels).
+ * group_div <= 8, G % group_div == 0, no head_quirk; FCMF_ERR_UNSUPPORTED otherwise (use fcmf_attn_small_bwd and sum). */
+int fcmf_attn_small_bwd_grouped(const fcmf_attn_desc* desc, const void* out, const void* dout,
+                                const float* lse, void* dq, void* dk1, void* dv1, void* dk2, void* dv2,
+                                float* dbias, float* scratch, int64_t scratch_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * MFMA self/cross attention for bf16, head dim 64, Tq, Tk <= 256 (the text-encoder layers: 128 tokens in FCMF-base,

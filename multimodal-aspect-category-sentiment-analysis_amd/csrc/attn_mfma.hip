@@ -120,6 +120,15 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
   *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16i .. 16i+15), result in every lane: four row rotations as DPP operands of
+// the adds -- no LDS crossbar traffic (ds_bpermute), which a __shfl_xor butterfly would cost
+__device__ __forceinline__ float row16_sum(float x) {
+#define FCMF_ROR_ADD(n) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xf, 0xf, true))
+  FCMF_ROR_ADD(8); FCMF_ROR_ADD(4); FCMF_ROR_ADD(2); FCMF_ROR_ADD(1);
+#undef FCMF_ROR_ADD
+  return x;
+}
+
 struct AttnMfmaParams {
   const bf16_t *q, *k, *v, *o, *dout;
   const float* mask;
@@ -541,9 +550,7 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
     const int HD = P.heads * AD;
     float* row = P.colsum + (int64_t)g * 3 * HD + h * AD;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { cV[r] += __shfl_xor(cV[r], o, 64); cK[r] += __shfl_xor(cK[r], o, 64); }
+    for (int r = 0; r < 4; ++r) { cV[r] = row16_sum(cV[r]); cK[r] = row16_sum(cK[r]); }
     if ((lane & 15) == 0) {      // d = 16 w + 4 (lane >> 4) + r: the workgroup owns these 64 columns of row g
       const int d0 = 16 * w + 4 * (lane >> 4);
 #pragma unroll
@@ -559,9 +566,7 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) t += aQ[qt][df][f];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) t[r] += __shfl_xor(t[r], o, 64);
+      for (int r = 0; r < 4; ++r) t[r] = row16_sum(t[r]);
       if ((lane & 15) == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[w * 64 + 16 * df + 4 * (lane >> 4) + r] = t[r];

@@ -9,17 +9,18 @@
 // Used for every attention on the path in fp32 (parity) mode and, in bf16 mode, for the dead-row-pruned
 // fusion layers (1 live query row per image), the 15-token fusion layer, the geometry-biased ROI attention
 // and the IAOG decoder; the bf16 text-encoder attention runs on attn_mfma.hip instead.
+#include <cstdlib>
 #include "common.h"
 
 constexpr int AS_MAXT = 512;   // T1 + T2 <= 512 (forward: KPL = 4 or 8 keys per lane; FCMF-large fuses 256 text + 100 ROI keys)
 constexpr int AS_MAXD = 128;   // head dim <= 128 (two elements per lane)
-constexpr int AS_NT1 = 32;     // shared keys per backward chunk <= 128: a wave accumulates keys w + 4n, n < 32
 
 struct AttnK {
   fcmf_attn_desc a;
   void* out; float* lse;
   const void* dout; const void* o_in;
   void *dq, *dk1, *dv1, *dk2, *dv2; float* dbias;
+  float *pd2, *ds2;            // backward, grouped private keys: [G][heads][R][T2] dropped probabilities / score gradients
   int RB;                      // query rows staged per block (host: what fits the LDS budget)
   int TLP;                     // pitch of the per-row key arrays of the backward (max keys a block sees)
   int KVF;                     // floats occupied by the staged shared K and V images
@@ -29,24 +30,25 @@ struct AttnK {
 // per lane, several rows per wave instruction, four instructions in flight per wave; otherwise lanes run across
 // the head dimension (coalesced) one row at a time.
 template <typename TT, typename TD>   // TD = float (converted) or TT (raw copy: shared keys/values stay in the activation dtype)
-__device__ __forceinline__ void stage_rows(TD* dst, int pitch, const TT* src, int64_t row_stride, int n, int d, int w, int lane) {
+__device__ __forceinline__ void stage_rows(TD* dst, int pitch, const TT* src, int64_t row_stride, int n, int d, int w, int lane,
+                                           int nw = 4) {
   constexpr int V = 16 / sizeof(TT);
   const bool vec = d % V == 0 && row_stride % V == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
   if (vec) {
     const int lpr = d / V, rpi = 64 / lpr;            // lanes per row, rows per wave instruction
     const int rl = lane / lpr, ch = lane - rl * lpr;
     const bool on = rl < rpi;
-    for (int t0 = w * rpi; t0 < n; t0 += 16 * rpi) {   // 4 waves x 4 instructions per round
+    for (int t0 = w * rpi; t0 < n; t0 += 4 * nw * rpi) {   // nw waves x 4 instructions per round
       uint4 v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int t = t0 + u * 4 * rpi + rl;
+        const int t = t0 + u * nw * rpi + rl;
         v[u] = make_uint4(0, 0, 0, 0);
         if (on && t < n) v[u] = *reinterpret_cast<const uint4*>(src + (int64_t)t * row_stride + ch * V);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int t = t0 + u * 4 * rpi + rl;
+        const int t = t0 + u * nw * rpi + rl;
         if (on && t < n) {
           TD* o = dst + t * pitch + ch * V;
           if constexpr (sizeof(TD) == sizeof(TT)) {
@@ -63,7 +65,7 @@ __device__ __forceinline__ void stage_rows(TD* dst, int pitch, const TT* src, in
       }
     }
   } else {
-    for (int t = w; t < n; t += 4) {
+    for (int t = w; t < n; t += nw) {
       const TT* sr = src + (int64_t)t * row_stride;
       for (int c = lane; c < d; c += 64) {
         if constexpr (sizeof(TD) == sizeof(TT)) dst[t * pitch + c] = sr[c];
@@ -138,19 +140,24 @@ __device__ __forceinline__ bool private_rows_vectorisable(const fcmf_attn_desc& 
          (reinterpret_cast<uintptr_t>(a.k2) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.v2) & 15) == 0;
 }
 
-template <typename TT, int KPL>
+// DC = head dimension when it is 64 (the text / fusion layers of FCMF: loops unroll, the 16-byte loads of a private key
+// row are all in flight together; 274 -> 120 us on the step's two fusion attentions), 0 = taken from the descriptor.
+// (Eight waves per workgroup -- one per query row of the 7-row fusion layers -- were measured slower than four.)
+template <typename TT, int KPL, int DC>
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
+  constexpr int NW = 4;
   constexpr int PMAX = 64 * KPL;          // keys a wave's probability row can hold
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const fcmf_attn_desc& a = P.a;
-  const int d = a.d, T1 = a.T1, T2 = a.T2, T = T1 + T2, RB = P.RB;
+  const int d = DC ? DC : a.d;
+  const int T1 = a.T1, T2 = a.T2, T = T1 + T2, RB = P.RB;
   constexpr int V16 = 16 / sizeof(TT);
   const bool v4 = d % V16 == 0;         // 16-byte LDS accesses throughout
   const int dp = v4 ? d + V16 : d + 1;  // K/V row pitch (elements): +16 B keeps 16-byte reads of 16 lanes on distinct banks; else odd
   TT* K1s = reinterpret_cast<TT*>(sm);
   TT* V1s = K1s + T1 * dp;
   float* Qs = sm + P.KVF;               // [RB][d] (KVF = floats taken by the two K/V images)
-  float* ps = Qs + RB * d;              // [4][PMAX] probability row of each wave
+  float* ps = Qs + RB * d;              // [NW][PMAX] probability row of each wave
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
   const int hin = a.head_quirk ? (int)(((int64_t)h * a.G + g) % a.heads) : h;
@@ -160,17 +167,17 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
   const TT* V2 = reinterpret_cast<const TT*>(a.v2);
   TT* O = reinterpret_cast<TT*>(P.out);
   if (T1 > 0) {
-    stage_rows<TT, TT>(K1s, dp, reinterpret_cast<const TT*>(a.k1) + (int64_t)g * a.k1_sg + hin * d, a.k1_st, T1, d, w, lane);
-    stage_rows<TT, TT>(V1s, dp, reinterpret_cast<const TT*>(a.v1) + (int64_t)g * a.k1_sg + hin * d, a.k1_st, T1, d, w, lane);
+    stage_rows<TT, TT>(K1s, dp, reinterpret_cast<const TT*>(a.k1) + (int64_t)g * a.k1_sg + hin * d, a.k1_st, T1, d, w, lane, NW);
+    stage_rows<TT, TT>(V1s, dp, reinterpret_cast<const TT*>(a.v1) + (int64_t)g * a.k1_sg + hin * d, a.k1_st, T1, d, w, lane, NW);
   }
   const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
   float* p = ps + w * PMAX;
   const bool vec2 = private_rows_vectorisable<TT>(a);
   for (int rb0 = 0; rb0 < a.R; rb0 += RB) {
     const int nr = min(RB, a.R - rb0);
-    stage_rows<TT, float>(Qs, d, Q + (int64_t)g * a.q_sg + (int64_t)rb0 * a.q_sr + hin * d, a.q_sr, nr, d, w, lane);
+    stage_rows<TT, float>(Qs, d, Q + (int64_t)g * a.q_sg + (int64_t)rb0 * a.q_sr + hin * d, a.q_sr, nr, d, w, lane, NW);
     __syncthreads();
-    for (int rl = w; rl < nr; rl += 4) {
+    for (int rl = w; rl < nr; rl += NW) {
       const int r = rb0 + rl;
       const float* q = Qs + rl * d;
       float sc[KPL];
@@ -240,7 +247,43 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
           if (lane + 64 < d) o1 += pv * to_f32<TT>(V1s[t * dp + lane + 64]);
         }
       }
-      if (T2 > 0) {
+      if (T2 > 0 && DC == 64 && sizeof(TT) == 2 && vec2) {
+        // private values, 16 bytes per lane: lane = (key t2 % 8, 8-dim slice): one wave instruction covers 8 keys x 64
+        // dims, every instruction of the row is in flight before the first use; the 8 key groups are then summed across
+        // lanes (lanes that share lane & 7 hold the same dims)
+        const TT* vb = V2 + (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + hin * d + (lane & 7) * 8;
+        const int kg = lane >> 3;
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 0; t0 < T2; t0 += 32) {
+          bf16x8 x[4];
+          float pw[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t2 = t0 + 8 * u + kg;
+            pw[u] = 0.f;
+            x[u] = bf16x8{};
+            if (t2 < T2) { x[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)t2 * a.k2_st); pw[u] = p[T1 + t2]; }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc8[j] += pw[u] * (float)x[u][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float t = acc8[j];
+          t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+          acc8[j] = t;
+        }
+        // lane l < 64 owns dim l: it sits in slice l >> 3, element l & 7 -- held by every lane with (lane & 7) == l >> 3
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = __shfl(acc8[j], lane >> 3, 64);     // from lane (l >> 3): its slice is l >> 3
+          if ((lane & 7) == j) mine = t;
+        }
+        o0 += mine;
+      } else if (T2 > 0) {
         const TT* vb = V2 + (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + hin * d;
 #pragma unroll 8
         for (int t2 = 0; t2 < T2; ++t2) {
@@ -264,8 +307,15 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnK P) {
 // chunks.  dk1/dv1 are dense [G,T1,heads*d].
 // ONE_BLOCK: all R rows fit one staged block (the usual case): dk1/dv1 are final after pass B and go straight
 // to memory; otherwise they accumulate in registers across the row blocks.
-template <typename TT, bool ONE_BLOCK>
+// Grouped private keys (P.pd2 != nullptr): rows of `group_div` consecutive groups share their private keys (the six
+// aspects of a review), so dk2 / dv2 are sums over the group.  Pass A then only stores the private keys' dropped
+// probabilities and score gradients (a few KB per workgroup) and attn_private_grad_kernel forms the sums -- instead of
+// one dk2 / dv2 row pair per (group, row, key) written here and summed by another pass (6x the bytes, twice).
+// (Four waves and a run-time head dimension: eight waves per workgroup and a compile-time d = 64 were both measured
+// SLOWER here -- 180 VGPRs instead of 88 halve the resident waves.)
+template <typename TT, bool ONE_BLOCK, bool GROUPED>
 __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
+  constexpr int NW = 4;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const fcmf_attn_desc& a = P.a;
   const int d = a.d, T1 = a.T1, T2 = a.T2, T = T1 + T2, RB = P.RB;
@@ -300,10 +350,10 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
   TT* dK2 = reinterpret_cast<TT*>(P.dk2);
   TT* dV2 = reinterpret_cast<TT*>(P.dv2);
   if (nsh > 0) {
-    stage_rows<TT, TT>(K1s, dp, reinterpret_cast<const TT*>(a.k1) + (int64_t)g * a.k1_sg + (int64_t)kc0 * a.k1_st + hin * d, a.k1_st, nsh, d, w, lane);
-    stage_rows<TT, TT>(V1s, dp, reinterpret_cast<const TT*>(a.v1) + (int64_t)g * a.k1_sg + (int64_t)kc0 * a.k1_st + hin * d, a.k1_st, nsh, d, w, lane);
+    stage_rows<TT, TT>(K1s, dp, reinterpret_cast<const TT*>(a.k1) + (int64_t)g * a.k1_sg + (int64_t)kc0 * a.k1_st + hin * d, a.k1_st, nsh, d, w, lane, NW);
+    stage_rows<TT, TT>(V1s, dp, reinterpret_cast<const TT*>(a.v1) + (int64_t)g * a.k1_sg + (int64_t)kc0 * a.k1_st + hin * d, a.k1_st, nsh, d, w, lane, NW);
   }
-  constexpr int NACC = ONE_BLOCK ? 1 : AS_NT1;
+  constexpr int NACC = ONE_BLOCK ? 1 : 128 / NW;      // shared keys of a chunk per wave: w + NW n
   float accK[NACC][2], accV[NACC][2];
 #pragma unroll
   for (int n = 0; n < NACC; ++n) { accK[n][0] = accK[n][1] = accV[n][0] = accV[n][1] = 0.f; }
@@ -313,11 +363,11 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
 
   for (int rb0 = 0; rb0 < a.R; rb0 += RB) {
     const int nr = min(RB, a.R - rb0);
-    stage_rows<TT, float>(Qs, d, Q + (int64_t)g * a.q_sg + (int64_t)rb0 * a.q_sr + hin * d, a.q_sr, nr, d, w, lane);
-    stage_rows<TT, float>(dOs, d, dO + (int64_t)g * a.o_sg + (int64_t)rb0 * a.o_sr + h * d, a.o_sr, nr, d, w, lane);
+    stage_rows<TT, float>(Qs, d, Q + (int64_t)g * a.q_sg + (int64_t)rb0 * a.q_sr + hin * d, a.q_sr, nr, d, w, lane, NW);
+    stage_rows<TT, float>(dOs, d, dO + (int64_t)g * a.o_sg + (int64_t)rb0 * a.o_sr + h * d, a.o_sr, nr, d, w, lane, NW);
     __syncthreads();
     // ---- pass A: wave = query row ---------------------------------------------------------------
-    for (int rl = w; rl < nr; rl += 4) {
+    for (int rl = w; rl < nr; rl += NW) {
       const int r = rb0 + rl;
       const float* q = Qs + rl * d;
       const float* dov = dOs + rl * d;
@@ -368,6 +418,11 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
           pd[tl] = pr * mult;
           ds[tl] = dsv;
           if (P.dbias) P.dbias[(((int64_t)g * a.heads + h) * a.R + r) * T + t] = dsv;
+          if (GROUPED && tl >= nsh) {
+            const int64_t i2 = (((int64_t)g * a.heads + h) * a.R + r) * T2 + (tl - nsh);
+            P.pd2[i2] = pr * mult;
+            P.ds2[i2] = dsv;
+          }
         }
       }
       // dq[c] = scale * sum_t ds[t] k[t][c]; private keys also get their dk2 / dv2 rows (outer products)
@@ -387,6 +442,49 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
           if (lane + 64 < d) dq1 += dsv * to_f32<TT>(K1s[tl * dp + lane + 64]);
         }
       }
+      if (GROUPED && T2c > 0 && d == 64 && sizeof(TT) == 2 && vec2) {
+        // grouped private keys: only dq needs them here.  16 bytes per lane, lane = (key t2 % 8, 8-dim slice): every load
+        // of the row is in flight before the first use; the 8 key groups are summed across lanes afterwards
+        const TT* kb = K2 + p2 + (lane & 7) * 8;
+        const int kg = lane >> 3;
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 0; t0 < T2c; t0 += 32) {
+          bf16x8 x[4];
+          float wgt[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t2 = t0 + 8 * u + kg;
+            wgt[u] = 0.f;
+            x[u] = bf16x8{};
+            if (t2 < T2c) { x[u] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)t2 * a.k2_st); wgt[u] = ds[nsh + t2]; }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc8[j] += wgt[u] * (float)x[u][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float t = acc8[j];
+          t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+          acc8[j] = t;
+        }
+        float mine = 0.f;          // lane l owns dim l = slice l >> 3, element l & 7
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = __shfl(acc8[j], lane >> 3, 64);
+          if ((lane & 7) == j) mine = t;
+        }
+        dq0 += mine;
+      } else if (GROUPED) {
+#pragma unroll 4
+        for (int t2 = 0; t2 < T2c; ++t2) {
+          const float dsv = ds[nsh + t2];
+          const TT* kr = K2 + p2 + (int64_t)t2 * a.k2_st;
+          if (lane < d) dq0 += dsv * to_f32<TT>(kr[lane]);
+          if (lane + 64 < d) dq1 += dsv * to_f32<TT>(kr[lane + 64]);
+        }
+      } else
 #pragma unroll 4
       for (int t2 = 0; t2 < T2c; ++t2) {
         const float dsv = ds[nsh + t2], pv = pd[nsh + t2];
@@ -430,7 +528,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
       }
     };
     if constexpr (ONE_BLOCK) {
-      for (int tl = w; tl < nsh; tl += 4) {
+      for (int tl = w; tl < nsh; tl += NW) {
         float k0, k1, v0, v1;
         key_sums(tl, k0, k1, v0, v1);
         write_key(tl, k0, k1, v0, v1);
@@ -438,7 +536,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
     } else {
 #pragma unroll
       for (int n = 0; n < NACC; ++n) {
-        const int tl = w + 4 * n;
+        const int tl = w + NW * n;
         if (tl < nsh) {
           float k0, k1, v0, v1;
           key_sums(tl, k0, k1, v0, v1);
@@ -449,10 +547,61 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
       if (rb0 + RB >= a.R) {
 #pragma unroll
         for (int n = 0; n < NACC; ++n) {
-          const int tl = w + 4 * n;
+          const int tl = w + NW * n;
           if (tl < nsh) write_key(tl, accK[n][0], accK[n][1], accV[n][0], accV[n][1]);
         }
       }
+    }
+  }
+}
+
+// dk2 / dv2 of grouped private keys: block = (g2, r) = one set of T2 private keys; thread = output column c (head c / d):
+//   dk2[g2][r][t2][c] = scale * sum_a ds2[g2*gd + a][head][r][t2] * q[g2*gd + a][r][c]
+//   dv2[g2][r][t2][c] =         sum_a pd2[...]                     * dO[g2*gd + a][r][c]
+// (pd2 / ds2 of the group staged in LDS as [a][head][t2]; every output row is one coalesced store)
+template <typename TT>
+__global__ __launch_bounds__(256) void attn_private_grad_kernel(AttnK P) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const fcmf_attn_desc& a = P.a;
+  const int d = a.d, T2 = a.T2, gd = a.group_div, heads = a.heads, HD = heads * d;
+  const int g2 = blockIdx.x / a.R, r = blockIdx.x % a.R;
+  const int tb = (T2 + gridDim.y - 1) / gridDim.y, t_lo = blockIdx.y * tb, t_hi = min(T2, t_lo + tb);   // this block's keys
+  float* PD = sm;                          // [gd][heads][T2]
+  float* DS = sm + gd * heads * T2;
+  for (int i = threadIdx.x; i < gd * heads * T2; i += 256) {
+    const int t2 = i % T2, ah = i / T2, hh = ah % heads, aa = ah / heads;
+    const int64_t src = ((((int64_t)g2 * gd + aa) * heads + hh) * a.R + r) * T2 + t2;
+    PD[i] = P.pd2[src];
+    DS[i] = P.ds2[src];
+  }
+  __syncthreads();
+  const TT* Q = reinterpret_cast<const TT*>(a.q);
+  const TT* dO = reinterpret_cast<const TT*>(P.dout);
+  TT* dK2 = reinterpret_cast<TT*>(P.dk2);
+  TT* dV2 = reinterpret_cast<TT*>(P.dv2);
+  for (int c = threadIdx.x; c < HD; c += 256) {
+    const int hh = c / d;
+    float qv[8], ov[8];
+#pragma unroll
+    for (int aa = 0; aa < 8; ++aa) {
+      qv[aa] = ov[aa] = 0.f;
+      if (aa < gd) {
+        const int64_t g = (int64_t)g2 * gd + aa;
+        qv[aa] = to_f32<TT>(Q[g * a.q_sg + (int64_t)r * a.q_sr + c]) * a.scale;
+        ov[aa] = to_f32<TT>(dO[g * a.o_sg + (int64_t)r * a.o_sr + c]);
+      }
+    }
+    const int64_t out0 = (((int64_t)g2 * a.R + r) * T2) * HD + c;
+    for (int t2 = t_lo; t2 < t_hi; ++t2) {
+      float kacc = 0.f, vacc = 0.f;
+#pragma unroll
+      for (int aa = 0; aa < 8; ++aa)
+        if (aa < gd) {
+          kacc += DS[(aa * heads + hh) * T2 + t2] * qv[aa];
+          vacc += PD[(aa * heads + hh) * T2 + t2] * ov[aa];
+        }
+      dK2[out0 + (int64_t)t2 * HD] = from_f32<TT>(kacc);
+      dV2[out0 + (int64_t)t2 * HD] = from_f32<TT>(vacc);
     }
   }
 }
@@ -488,29 +637,35 @@ extern "C" int fcmf_attn_small_fwd(const fcmf_attn_desc* desc, void* out, float*
   const size_t esz = desc->dtype == FCMF_F32 ? 4 : 2;
   P.KVF = (int)((2 * (size_t)desc->T1 * (desc->d + 16 / esz) * esz + 15) / 16 * 4);   // K and V images, rounded to 16 B, in floats
   const int kpl = desc->T1 + desc->T2 <= 256 ? 4 : 8;     // keys per lane of the forward
-  const size_t base = sizeof(float) * ((size_t)P.KVF + 4 * 64 * kpl);
+  const int nw = 4;
+  const size_t base = sizeof(float) * ((size_t)P.KVF + (size_t)nw * 64 * kpl);
   const size_t per_row = sizeof(float) * (size_t)desc->d;
   P.RB = rows_per_block(desc->R, base, per_row);
   if (P.RB <= 0) return FCMF_ERR_UNSUPPORTED;
   const size_t smem = base + (size_t)P.RB * per_row;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(desc->G * desc->heads);
-#define FCMF_ATTN_FWD(TT, KPL)                                                                                             \
+#define FCMF_ATTN_FWD(TT, KPL, DC)                                                                                         \
   do {                                                                                                                     \
-    auto k = attn_small_fwd_kernel<TT, KPL>;                                                                               \
+    auto k = attn_small_fwd_kernel<TT, KPL, DC>;                                                                           \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
     hipLaunchKernelGGL(k, grid, dim3(256), smem, st, P);                                                                   \
   } while (0)
-  if (desc->dtype == FCMF_F32) { if (kpl == 4) FCMF_ATTN_FWD(float, 4); else FCMF_ATTN_FWD(float, 8); }
-  else { if (kpl == 4) FCMF_ATTN_FWD(bf16_t, 4); else FCMF_ATTN_FWD(bf16_t, 8); }
+#define FCMF_ATTN_FWD_T(TT)                                                                                                \
+  do {                                                                                                                     \
+    if (desc->d == 64) { if (kpl == 4) FCMF_ATTN_FWD(TT, 4, 64); else FCMF_ATTN_FWD(TT, 8, 64); }                          \
+    else               { if (kpl == 4) FCMF_ATTN_FWD(TT, 4, 0); else FCMF_ATTN_FWD(TT, 8, 0); }                            \
+  } while (0)
+  if (desc->dtype == FCMF_F32) FCMF_ATTN_FWD_T(float); else FCMF_ATTN_FWD_T(bf16_t);
+#undef FCMF_ATTN_FWD_T
 #undef FCMF_ATTN_FWD
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
 
-extern "C" int fcmf_attn_small_bwd(const fcmf_attn_desc* desc, const void* out, const void* dout, const float* lse,
-                                   void* dq, void* dk1, void* dv1, void* dk2, void* dv2, float* dbias,
-                                   void* stream) {
+static int attn_small_bwd_impl(const fcmf_attn_desc* desc, const void* out, const void* dout, const float* lse,
+                               void* dq, void* dk1, void* dv1, void* dk2, void* dv2, float* dbias,
+                               float* scratch, int64_t scratch_bytes, void* stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
   if (!out || !dout || !lse || !dq) return FCMF_ERR_ARG;
@@ -520,6 +675,15 @@ extern "C" int fcmf_attn_small_bwd(const fcmf_attn_desc* desc, const void* out, 
   AttnK P{};
   P.a = *desc; P.o_in = out; P.dout = dout; P.lse = const_cast<float*>(lse);
   P.dq = dq; P.dk1 = dk1; P.dv1 = dv1; P.dk2 = dk2; P.dv2 = dv2; P.dbias = dbias;
+  const bool grouped = scratch != nullptr;
+  const int64_t n2 = (int64_t)desc->G * desc->heads * desc->R * desc->T2;
+  const size_t smem2 = sizeof(float) * 2 * (size_t)desc->group_div * desc->heads * desc->T2;
+  if (grouped) {
+    if (desc->T2 <= 0 || desc->group_div > 8 || desc->G % desc->group_div || desc->head_quirk || smem2 > 150 * 1024)
+      return FCMF_ERR_UNSUPPORTED;
+    if (scratch_bytes < 2 * n2 * (int64_t)sizeof(float)) return FCMF_ERR_ARG;
+    P.pd2 = scratch; P.ds2 = scratch + n2;
+  }
   const int nsh = desc->T1 < 128 ? desc->T1 : 128;
   const size_t esz = desc->dtype == FCMF_F32 ? 4 : 2;
   P.KVF = (int)((2 * (size_t)nsh * (desc->d + 16 / esz) * esz + 15) / 16 * 4);
@@ -533,15 +697,46 @@ extern "C" int fcmf_attn_small_bwd(const fcmf_attn_desc* desc, const void* out, 
   const int nchunks = desc->T1 > 0 ? (desc->T1 + 127) / 128 : 1;
   dim3 grid(desc->G * desc->heads, nchunks);
   const bool one = P.RB >= desc->R;
-#define LAUNCH_(T, ONE)                                                                                                    \
+#define LAUNCH_(T, ONE, GR)                                                                                                \
   do {                                                                                                                     \
-    auto k = attn_small_bwd_kernel<T, ONE>;                                                                                \
+    auto k = attn_small_bwd_kernel<T, ONE, GR>;                                                                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
     hipLaunchKernelGGL(k, grid, dim3(256), smem, st, P);                                                                   \
   } while (0)
-  if (desc->dtype == FCMF_F32) { if (one) LAUNCH_(float, true); else LAUNCH_(float, false); }
-  else { if (one) LAUNCH_(bf16_t, true); else LAUNCH_(bf16_t, false); }
+#define LAUNCH_T(T)                                                                                                        \
+  do {                                                                                                                     \
+    if (grouped) { if (one) LAUNCH_(T, true, true); else LAUNCH_(T, false, true); }                                        \
+    else         { if (one) LAUNCH_(T, true, false); else LAUNCH_(T, false, false); }                                      \
+  } while (0)
+  if (desc->dtype == FCMF_F32) LAUNCH_T(float); else LAUNCH_T(bf16_t);
+#undef LAUNCH_T
 #undef LAUNCH_
   FCMF_CHECK_LAUNCH();
+  if (grouped) {
+    dim3 grid2((desc->G / desc->group_div) * desc->R, 4);    // 4 key ranges per (review, row): ~1800 workgroups on the step
+    if (desc->dtype == FCMF_F32) {
+      auto k = attn_private_grad_kernel<float>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+      hipLaunchKernelGGL(k, grid2, dim3(256), smem2, st, P);
+    } else {
+      auto k = attn_private_grad_kernel<bf16_t>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+      hipLaunchKernelGGL(k, grid2, dim3(256), smem2, st, P);
+    }
+    FCMF_CHECK_LAUNCH();
+  }
   return FCMF_OK;
+}
+
+extern "C" int fcmf_attn_small_bwd(const fcmf_attn_desc* desc, const void* out, const void* dout, const float* lse,
+                                   void* dq, void* dk1, void* dv1, void* dk2, void* dv2, float* dbias,
+                                   void* stream) {
+  return attn_small_bwd_impl(desc, out, dout, lse, dq, dk1, dv1, dk2, dv2, dbias, nullptr, 0, stream);
+}
+
+extern "C" int fcmf_attn_small_bwd_grouped(const fcmf_attn_desc* desc, const void* out, const void* dout, const float* lse,
+                                           void* dq, void* dk1, void* dv1, void* dk2, void* dv2, float* dbias,
+                                           float* scratch, int64_t scratch_bytes, void* stream) {
+  if (!scratch) return FCMF_ERR_ARG;
+  return attn_small_bwd_impl(desc, out, dout, lse, dq, dk1, dv1, dk2, dv2, dbias, scratch, scratch_bytes, stream);
 }

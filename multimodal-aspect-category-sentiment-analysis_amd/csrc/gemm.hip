@@ -1354,8 +1354,15 @@ extern "C" int fcmf_colsum(const void* X, float* out, int M, int N, int64_t ldx,
   if (!accumulate) { if (hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) return FCMF_ERR_LAUNCH; }
   if (M == 0) return FCMF_OK;
   const int vec = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  // rows per block: 256, or ~1024 blocks of >= 16 rows where 256-row blocks would not fill the chip (a 384-row matrix on
+  // 18 blocks took 27 us: every wave walks its rows one dependent load at a time)
+  const int bx = (N + 255) / 256;
   int rpb = 256;
-  dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+  if ((int64_t)((M + 255) / 256) * bx < 256) {       // fewer blocks than CUs: shorter row runs
+    rpb = (int)(((int64_t)M * bx / 1024 + 3) & ~3ll);
+    rpb = rpb < 16 ? 16 : (rpb > 256 ? 256 : rpb);
+  }
+  dim3 grid(bx, (M + rpb - 1) / rpb);
   if (dtype == FCMF_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)X, out, M, N, ldx, rpb, vec);
   else if (dtype == FCMF_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)X, out, M, N, ldx, rpb, vec);
   else return FCMF_ERR_UNSUPPORTED;

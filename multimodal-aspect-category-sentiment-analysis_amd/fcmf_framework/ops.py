@@ -826,18 +826,27 @@ class AttentionFn(torch.autograd.Function):
             dk1 = torch.empty((G, T1, HD), dtype=k1.dtype, device=q.device)
             dv1 = torch.empty((G, T1, HD), dtype=k1.dtype, device=q.device)
         T2 = 0 if k2 is None else k2.shape[2]
+        # private keys shared by `group_div` groups: the library sums their gradients over the group (no per-group rows)
+        grouped = k2 is not None and group_div <= 8 and G % group_div == 0
         if k2 is not None:
-            dk2 = torch.empty((G, R, T2, HD), dtype=q.dtype, device=q.device)
-            dv2 = torch.empty((G, R, T2, HD), dtype=q.dtype, device=q.device)
+            G2 = G // group_div if grouped else G
+            dk2 = torch.empty((G2, R, T2, HD), dtype=q.dtype, device=q.device)
+            dv2 = torch.empty((G2, R, T2, HD), dtype=q.dtype, device=q.device)
         if bias is not None and ctx.needs_input_grad[6]:
             T = (0 if k1 is None else k1.shape[1]) + T2
             dbias = torch.empty((G, heads, R, T), dtype=torch.float32, device=q.device)
         a = _desc(q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal, 0)
-        H.check(H.lib().fcmf_attn_small_bwd(a, H.ptr(out), H.ptr(dout), H.ptr(lse), H.ptr(dq), H.ptr(dk1), H.ptr(dv1),
-                                            H.ptr(dk2), H.ptr(dv2), H.ptr(dbias), H.stream()), "fcmf_attn_small_bwd")
+        if grouped:
+            scratch = torch.empty(2 * G * heads * R * T2, dtype=torch.float32, device=q.device)
+            H.check(H.lib().fcmf_attn_small_bwd_grouped(a, H.ptr(out), H.ptr(dout), H.ptr(lse), H.ptr(dq), H.ptr(dk1), H.ptr(dv1),
+                                                        H.ptr(dk2), H.ptr(dv2), H.ptr(dbias), H.ptr(scratch), scratch.numel() * 4,
+                                                        H.stream()), "fcmf_attn_small_bwd_grouped")
+        else:
+            H.check(H.lib().fcmf_attn_small_bwd(a, H.ptr(out), H.ptr(dout), H.ptr(lse), H.ptr(dq), H.ptr(dk1), H.ptr(dv1),
+                                                H.ptr(dk2), H.ptr(dv2), H.ptr(dbias), H.stream()), "fcmf_attn_small_bwd")
         dq = _sum_leading(dq)
         if group_div > 1:
-            if dk2 is not None:
+            if dk2 is not None and not grouped:
                 dk2, dv2 = _sum_groups(dk2, group_div), _sum_groups(dv2, group_div)
             if dbias is not None:
                 dbias = _sum_groups(dbias, group_div)

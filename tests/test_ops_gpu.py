@@ -306,6 +306,10 @@ ATTN_CASES = [
     (3, 6, 4, 16, 6, 0, 1, False, False, True),       # causal fill (IAOG decoder)
     (1, 150, 2, 64, 130, 20, 1, True, False, False),  # rows staged in several blocks x two key chunks x private keys
     (2, 40, 3, 20, 33, 5, 2, True, True, False),      # head dim not a multiple of 8: scalar staging / dot paths, bias + groups
+    (12, 7, 3, 64, 128, 36, 6, True, False, False),   # the step's text+ROI layer: 6 aspects share the 36 private ROI keys (8 waves, d = 64)
+    (12, 7, 3, 64, 0, 49, 6, True, False, False),     # the step's text->patch cross attention: private keys only, 6 aspects per review
+    (6, 5, 2, 64, 40, 70, 3, True, False, False),     # > 64 private keys: three rounds of the 16-byte private-key walk
+    (16, 3, 2, 16, 10, 7, 16, True, False, False),    # group of 16 > 8: per-group rows + host-side sum (ungrouped fallback)
 ]
 
 
