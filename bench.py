@@ -212,8 +212,8 @@ def run_fcmf(args, rank, world, dev, large=False):
     opt = FusedAdamW(param_groups(model), lr=7e-4)
     sched = get_linear_schedule_with_warmup(opt, int(0.1 * 1000), 1000)
     red = arena = None
-    if world > 1 or args.arena:
-        arena = GradArena.for_model(model)     # (leaves out bert.cell.pooler: it never gets a gradient)
+    if world > 1 or not args.no_arena:
+        arena = GradArena.for_model(model)     # as run_multimodal_fcmf.py does (leaves out bert.cell.pooler: it never gets a gradient)
         if world > 1:
             red = GradReducer(arena)
             red.broadcast_parameters(0)
@@ -384,7 +384,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
-    ap.add_argument("--arena", action="store_true", help="single GPU: also use the flat gradient arena (always on for --gpus > 1)")
+    ap.add_argument("--no-arena", dest="no_arena", action="store_true",
+                    help="single GPU: per-weight gradient tensors instead of the flat gradient arena the drivers use (always on for --gpus > 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
