@@ -215,7 +215,9 @@ __device__ __forceinline__ void attn_mfma_fwd_tile(const AttnMfmaParams& P, int 
 #pragma unroll
     for (int kf = 0; kf < NKF; ++kf) {
       float dm[4] = {1.f, 1.f, 1.f, 1.f};
-      if (P.p > 0.f) dropout_mult4(P.seed, (((uint64_t)g * P.heads + h) * P.Tq + q) * P.Tk + 16 * kf + 4 * (lane >> 4), P.p, inv_keep, dm);
+      if (P.p > 0.f)
+        dropout_mult4(P.seed, ((uint64_t)g * P.heads + h) * P.Tq * P.Tk + (__umul24((unsigned)q, (unsigned)P.Tk) + (unsigned)(16 * kf + 4 * (lane >> 4))),
+                      P.p, inv_keep, dm);
 #pragma unroll
       for (int r = 0; r < 4; ++r) sc[kf][f][r] = sc[kf][f][r] * inv * dm[r];
     }
@@ -415,6 +417,7 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
   __syncthreads();
 
   const float inv_keep = P.p > 0.f ? 1.0f / (1.0f - P.p) : 1.0f;
+  const uint64_t drop_base = ((uint64_t)g * P.heads + h) * P.Tq * P.Tk;      // dropout counter of (query 0, key 0)
   const float* mrow = P.mask ? P.mask + kbase : nullptr;
   // operands that stay in registers, per query tile: the wave's 32 query rows of Q and dO (phase 1) and the transposed
   // 16-column slices dO^T / Q^T [d = 16w ..][q] that dV / dK of every key chunk multiply (phase 2)
@@ -480,7 +483,9 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
             const int q = qt * AT + 32 * w + 16 * f + 4 * (lane >> 4) + r;
             float pr = 0.f, mult = 1.0f;
             if (key < P.Tk && q < P.Tq) pr = __expf(sS[k4][f][r] * P.scale + mk - lse4[qt][f][r]);
-            if (P.p > 0.f) mult = dropout_mult(P.seed, (((uint64_t)g * P.heads + h) * P.Tq + q) * P.Tk + key, P.p, inv_keep);
+            // element index ((g heads + h) Tq + q) Tk + key = a wave-uniform 64-bit base + a small 24-bit product: no
+            // 64-bit vector multiply per element (integer multiplies are quarter rate; the kernel is VALU-bound)
+            if (P.p > 0.f) mult = dropout_mult(P.seed, drop_base + (__umul24((unsigned)q, (unsigned)P.Tk) + (unsigned)key), P.p, inv_keep);
             pdv[r] = pr * mult;
             dsv[r] = pr * (sP[k4][f][r] * mult - dl4[qt][f][r]);
           }

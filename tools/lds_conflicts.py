@@ -86,3 +86,9 @@ if __name__ == "__main__":
                 a.append(kk * 256 + ((f ^ tk(kk)) << 5) + ((p >> 1) << 4) + ((p & 1) << 3))
             wt = max(wt, read_tr_b64(a))
     print("GEMM 256B-row tr tile: tr read", wt, "way")
+    # ---- GEMM 64-deep k-tiles (csrc/gemm.hip, KB = 64): [256 rows][64 k] tile, 128-B rows, chunk ^ ((row >> 1) & 7);
+    #      fragment f, k-half h: row 16 f + (lane & 15), logical chunk 4 h + (lane >> 4)
+    off64 = lambda r, c: r * 128 + ((c ^ ((r >> 1) & 7)) << 4)
+    w64 = max(read_b128([off64(16 * f + (l & 15), 4 * h + (l >> 4)) for l in range(64)]) for f in range(16) for h in range(2))
+    print("GEMM 128B-row tile (64-deep k-tiles): row read", w64, "way")
+    assert w64 == 1
