@@ -1,5 +1,5 @@
 """Calibration only (never on the product path): the step's big GEMM shapes through torch.matmul (hipBLASLt / rocBLAS)
-and through fcmf_gemm, same operands, HIP-event timed.  Tells how far the hand-written kernels are from the vendor's
+and through fcmf_gemm (weight gradients: accumulate = 1, as the step issues them), same operands, HIP-event timed.  Tells how far the hand-written kernels are from the vendor's
 best on THESE shapes.  Run on the GPU box: python tools/blaslt_calib.py > gpurun_out/blaslt_calib.txt"""
 import importlib
 import os
@@ -47,7 +47,11 @@ for name, M, N, K, ta, tb in SHAPES:
     opA = A.t() if ta else A
     opB = B if tb else B.t()
     t_lt = timeit(lambda: torch.matmul(opA, opB, out=Cb))
-    t_my = timeit(lambda: ops.gemm(A, B, C, M, N, K, A.stride(0), B.stride(0), C.stride(0), bool(ta), bool(tb)))
+    # weight gradients as the step issues them: accumulate into an f32 gradient (split-K through the registered workspace)
+    t_my = timeit(lambda: ops.gemm(A, B, C, M, N, K, A.stride(0), B.stride(0), C.stride(0), bool(ta), bool(tb), acc=bool(ta)))
+    if ta:
+        C.zero_()
+        ops.gemm(A, B, C, M, N, K, A.stride(0), B.stride(0), C.stride(0), True, bool(tb), acc=True)
     ref = torch.matmul(opA.float()[:256], opB.float())
     err = (C[:256].float() - ref).abs().max().item() / ref.abs().max().item()
     fl = 2.0 * M * N * K
