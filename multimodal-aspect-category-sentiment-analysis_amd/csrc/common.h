@@ -27,10 +27,16 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return
 // 4-wide vector load/store of T as float4 (T = float: 16 B, T = bf16: 8 B)
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
+  typedef float4 raw;      // as loaded, before conversion (software-pipelined loops hold the next row in this form)
+  static __device__ __forceinline__ raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ float4 cvt(raw v) { return v; }
   static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
   static __device__ __forceinline__ void store(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 };
 template <> struct Vec4<bf16_t> {
+  typedef bf16x4 raw;
+  static __device__ __forceinline__ raw load_raw(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+  static __device__ __forceinline__ float4 cvt(raw v) { return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]); }
   static __device__ __forceinline__ float4 load(const bf16_t* p) {
     bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);

@@ -1057,7 +1057,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
   const int r1 = min(M, r0 + rows_per_block);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (vec && col + 3 < N) {
-    for (int r = r0 + wave; r < r1; r += 4) {
+    int r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {        // four rows in flight per wave (one dependent load per iteration is latency-bound)
+      const float4 v0 = Vec4<T>::load(X + (int64_t)r * ldx + col), v1 = Vec4<T>::load(X + (int64_t)(r + 4) * ldx + col);
+      const float4 v2 = Vec4<T>::load(X + (int64_t)(r + 8) * ldx + col), v3 = Vec4<T>::load(X + (int64_t)(r + 12) * ldx + col);
+      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+      s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; r < r1; r += 4) {
       const float4 v = Vec4<T>::load(X + (int64_t)r * ldx + col);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }

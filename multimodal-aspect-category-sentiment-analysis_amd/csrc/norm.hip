@@ -14,16 +14,38 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
                                                          float* __restrict__ rstd, int rows, int H, float eps,
                                                          float p, uint64_t seed) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
   const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  // grid-stride over rows with a one-row software pipeline: the next row's x (+res) is requested before the current
+  // row's two wave reductions and stores
+  typedef typename Vec4<T>::raw Raw;
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  Raw nx[NP], nr[NP];
+  auto fetch = [&](int r) {
+    if (r < rows) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < H) {
+          nx[i] = Vec4<T>::load_raw(x + (int64_t)r * H + c);
+          if (res) nr[i] = Vec4<T>::load_raw(res + (int64_t)r * res_stride + c);
+        }
+      }
+    }
+  };
+  fetch(row);
+  for (; row < rows; row += stride) {
+  Raw cx[NP], cr[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) { cx[i] = nx[i]; cr[i] = nr[i]; }
+  fetch(row + stride);
   float4 v[NP];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < H) {
-      float4 a = Vec4<T>::load(x + (int64_t)row * H + c);
+      float4 a = Vec4<T>::cvt(cx[i]);
       if (p > 0.f) {
         const uint64_t base = (uint64_t)row * H + c;
         float dm[4];
@@ -31,7 +53,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
         a.x *= dm[0]; a.y *= dm[1]; a.z *= dm[2]; a.w *= dm[3];
       }
       if (res) {
-        float4 r = Vec4<T>::load(res + (int64_t)row * res_stride + c);
+        float4 r = Vec4<T>::cvt(cr[i]);
         a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
       }
       v[i] = a;
@@ -63,11 +85,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
       Vec4<T>::store(y + (int64_t)row * H + c, o);
     }
   }
+  }
 }
 
-// Backward: dz = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)).  dgamma/dbeta are summed
-// over the rows a block walks in registers, across its 4 waves through LDS, then one float
-// atomic per column per block.
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                          const float* __restrict__ gamma,
@@ -87,16 +107,38 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
     const int c = (i * 64 + lane) * 4;
     gm[i] = c < H ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0, 0, 0, 0);
   }
-  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
+  // software pipeline over the wave's rows: the NEXT row's dy / z (and statistics) are requested before the current row is
+  // reduced, so the two dependent wave reductions and the stores of a row overlap the next row's memory latency
+  typedef typename Vec4<T>::raw Raw;
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + w;
+  Raw nd[NP], nz[NP];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](int r) {
+    if (r < rows) {
+      nmu = mean[r]; nrs = rstd[r];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < H) { nd[i] = Vec4<T>::load_raw(dy + (int64_t)r * H + c); nz[i] = Vec4<T>::load_raw(z + (int64_t)r * H + c); }
+      }
+    }
+  };
+  fetch(row);
+  for (; row < rows; row += stride) {
+    const float mu = nmu, rs = nrs;
+    Raw cd[NP], cz[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { cd[i] = nd[i]; cz[i] = nz[i]; }
+    fetch(row + stride);
     float4 gy[NP], xh[NP];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < H) {
-        const float4 d = Vec4<T>::load(dy + (int64_t)row * H + c);
-        const float4 zz = Vec4<T>::load(z + (int64_t)row * H + c);
+        const float4 d = Vec4<T>::cvt(cd[i]);
+        const float4 zz = Vec4<T>::cvt(cz[i]);
         float4 h; h.x = (zz.x - mu) * rs; h.y = (zz.y - mu) * rs; h.z = (zz.z - mu) * rs; h.w = (zz.w - mu) * rs;
         ag[i].x += d.x * h.x; ag[i].y += d.y * h.y; ag[i].z += d.z * h.z; ag[i].w += d.w * h.w;
         ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
@@ -367,7 +409,8 @@ extern "C" int fcmf_add_ln_fwd(const void* x, const void* res, int64_t res_strid
   if (H % 4 != 0 || H > LN_MAXP * 256 || (res && res_stride % 4 != 0)) return FCMF_ERR_UNSUPPORTED;
   if (rows == 0) return FCMF_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid((rows + 3) / 4);
+  const int nblk = (rows + 3) / 4;
+  dim3 grid(nblk > 2048 ? 2048 : nblk);      // 8 workgroups per CU; every wave walks its rows with the next one in flight
   if (dtype != FCMF_F32 && dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
 #define LAUNCH_(T, NP) hipLaunchKernelGGL((add_ln_fwd_kernel<T, NP>), grid, dim3(256), 0, st, (const T*)x, (const T*)res, \
     res_stride, gamma, beta, (T*)y, (T*)z, mean, rstd, rows, H, eps, dropout_p, seed)
