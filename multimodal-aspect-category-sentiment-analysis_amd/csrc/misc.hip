@@ -285,7 +285,31 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(AdamArgs a) {
     coef = fminf(1.0f, a.max_norm / (tn + 1e-6f));
   }
   const float step_size = lr / a.bc1;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
+  // 16 bytes per lane where the chunk allows; the moments and the gradient are touched once per step: nontemporal
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  int64_t i0 = 0;
+  if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
+      (!sh || (reinterpret_cast<uintptr_t>(sh) & 7) == 0)) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      const f4 g4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i) * coef;
+      f4 p4 = reinterpret_cast<const f4*>(p)[i] * (1.0f - lr * wd);
+      const f4 m4 = a.beta1 * __builtin_nontemporal_load(reinterpret_cast<const f4*>(m) + i) + (1.0f - a.beta1) * g4;
+      const f4 v4 = a.beta2 * __builtin_nontemporal_load(reinterpret_cast<const f4*>(v) + i) + (1.0f - a.beta2) * g4 * g4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p4[e] -= step_size * (m4[e] / (sqrtf(v4[e]) / a.bc2_sqrt + a.eps));
+      reinterpret_cast<f4*>(p)[i] = p4;
+      __builtin_nontemporal_store(m4, reinterpret_cast<f4*>(m) + i);
+      __builtin_nontemporal_store(v4, reinterpret_cast<f4*>(v) + i);
+      if (sh) {
+        bf16x4 o;
+        o[0] = (bf16_t)p4[0]; o[1] = (bf16_t)p4[1]; o[2] = (bf16_t)p4[2]; o[3] = (bf16_t)p4[3];
+        reinterpret_cast<bf16x4*>(sh)[i] = o;
+      }
+    }
+    i0 = n4 << 2;
+  }
+  for (int64_t i = i0 + threadIdx.x; i < n; i += 256) {
     const float gi = g[i] * coef;
     float pi = p[i] * (1.0f - lr * wd);
     const float mi = a.beta1 * m[i] + (1.0f - a.beta1) * gi;

@@ -1,6 +1,5 @@
-L=multimodal-aspect-category-sentiment-analysis_amd/fcmf_framework/libfcmf_hip.so
-cp $L /tmp/prod.so
-run() { python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"ms_per_step\"])"; }
-echo product; run
-for v in ln_z ln_zy ln_zdz ln_all; do cp tools/bin/$v/libfcmf_hip.so $L; echo $v; run; run; done
-cp /tmp/prod.so $L; echo product; run
+timeout -k 10 600 python -m pytest tests/test_ops_gpu.py tests/test_parity_gpu.py -q -x -k "adam or optim or parity or golden or step or resume" > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
+tail -2 gpurun_out/t.log
+ROOT=$(pwd); cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/abp -o p -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $ROOT/gpurun_out/abp.log 2>&1
+grep -E "adamw|sumsq|cast_transpose" $ROOT/gpurun_out/abp/p_kernel_stats.csv | cut -c1-140
