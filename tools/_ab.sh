@@ -1,5 +1,5 @@
-timeout -k 10 600 python -m pytest tests/test_ops_gpu.py tests/test_parity_gpu.py -q -x -k "adam or optim or parity or golden or step or resume" > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
-tail -2 gpurun_out/t.log
-ROOT=$(pwd); cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/abp -o p -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $ROOT/gpurun_out/abp.log 2>&1
-grep -E "adamw|sumsq|cast_transpose" $ROOT/gpurun_out/abp/p_kernel_stats.csv | cut -c1-140
+B=tools/bin/gemm_bench
+for m in 0 8 0 8; do echo "## XCD_MAP=$m"; FCMF_GEMM_XCD_MAP=$m $B 10 0 "fwd  ffn1"; FCMF_GEMM_XCD_MAP=$m $B 10 0 "dX   ffn2"; done
+run() { python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"ms_per_step\"])"; }
+for m in 0 8 0 8; do echo "step XCD_MAP=$m"; FCMF_GEMM_XCD_MAP=$m run; done
+FCMF_GEMM_XCD_MAP=8 timeout -k 10 300 python -m pytest tests/test_ops_gpu.py -q -x -k gemm 2>&1 | tail -2
