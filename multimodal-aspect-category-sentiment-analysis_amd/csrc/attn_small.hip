@@ -1,15 +1,16 @@
 // Two-segment multi-head attention, forward and backward, VALU f32 math, any activation dtype.
 // One workgroup = one (group g, head h).  The T1 shared keys/values and a block of query rows (with dO in
 // the backward) are staged once in LDS; one WAVE owns one query row at a time: its scores over the shared
-// keys run one key per lane out of LDS, its T2 private keys/values stream from global memory one key per
-// step with the head dimension across the lanes (coalesced rows, one wave reduction per key).  The
+// keys run one key per lane out of LDS, its T2 private keys are scored one key per lane (the lane walks its key's
+// row with 16-byte loads) and their values / keys are accumulated 8 keys x 64 dims per wave instruction (head
+// dim 64) or one key per step with the head dimension across the lanes (other head dims).  The
 // backward is two passes per row block: pass A (wave = row) builds the dropped probabilities and score
-// gradients [row][key] in LDS and finishes dq / dk2 / dv2 / dbias, pass B (wave = shared key) reduces them
-// over the rows into dk1 / dv1 -- two workgroup barriers per row block, no per-row global round trips.
+// gradients [row][key] in LDS and finishes dq / dbias (and dk2 / dv2 rows, unless the private keys are shared by a
+// group of sequences: then attn_private_grad_kernel sums them over the group), pass B (wave = shared key) reduces
+// them over the rows into dk1 / dv1 -- two workgroup barriers per row block, no per-row global round trips.
 // Used for every attention on the path in fp32 (parity) mode and, in bf16 mode, for the dead-row-pruned
 // fusion layers (1 live query row per image), the 15-token fusion layer, the geometry-biased ROI attention
 // and the IAOG decoder; the bf16 text-encoder attention runs on attn_mfma.hip instead.
-#include <cstdlib>
 #include "common.h"
 
 constexpr int AS_MAXT = 512;   // T1 + T2 <= 512 (forward: KPL = 4 or 8 keys per lane; FCMF-large fuses 256 text + 100 ROI keys)

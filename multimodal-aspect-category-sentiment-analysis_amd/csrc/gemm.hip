@@ -334,7 +334,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 // allocation of the main loop clean (2 waves/SIMD -> 256 VGPRs, 128 of them accumulators).
 // =========================================================================================
 constexpr int GB = 256;                       // block tile rows and columns
-constexpr int RING_BYTES = 128 * 1024;        // operand ring: 4 stages of 32-deep k-tiles or 2 stages of 64-deep k-tiles
+constexpr int RING_BYTES = 128 * 1024;        // operand ring of the 32-deep k-tile kernels: 4 stages of (A tile + B tile); the epilogue's
+                                              // transposition slices lie above it.  The 64-deep kernels use all 160 KiB as five operand slots.
 
 // Image of a K-contiguous operand tile with 64-deep k-tiles [256 rows][64 k] (128-B rows = whole cache lines):
 // 16-B chunk c (0..7) stored at c ^ ((row >> 1) & 7): the ds_read_b128 fragment reads of either k-half are

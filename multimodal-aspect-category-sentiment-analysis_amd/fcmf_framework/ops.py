@@ -618,20 +618,20 @@ class AddLNFn(torch.autograd.Function):
         H.check(H.lib().fcmf_add_ln_fwd(H.ptr(x2), H.ptr(r2), 0 if r2 is None else _ld(r2), H.ptr(gamma), H.ptr(beta),
                                         H.ptr(y), H.ptr(z), H.ptr(mean), H.ptr(rstd), rows, Hd, eps, p, seed,
                                         H.dt(x2), H.stream()), "fcmf_add_ln_fwd")
-        ctx.save_for_backward(z, gamma, mean, rstd)
+        ctx.save_for_backward(z, gamma, mean, rstd, beta)
         ctx.p, ctx.seed, ctx.xshape = p, seed, x.shape
         ctx.res_shape = None if res is None else res.shape
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        z, gamma, mean, rstd = ctx.saved_tensors
+        z, gamma, mean, rstd, beta = ctx.saved_tensors
         rows, Hd = z.shape
         dy2 = dy.reshape(rows, Hd).contiguous()
         dz = torch.empty_like(z)
         dx = torch.empty_like(z) if ctx.p > 0 else None
-        dg = torch.zeros(Hd, dtype=torch.float32, device=z.device)
-        db = torch.zeros(Hd, dtype=torch.float32, device=z.device)
+        dg = alloc_grad(gamma, (Hd,))       # the arena slices (already zero) where an arena is active: no fill launches
+        db = alloc_grad(beta, (Hd,))
         H.check(H.lib().fcmf_add_ln_bwd(H.ptr(dy2), H.ptr(z), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(dz),
                                         H.ptr(dx), H.ptr(dg), H.ptr(db), 0, H.ptr(ln_workspace(rows, Hd, z.device)), rows, Hd, ctx.p, ctx.seed, H.dt(z),
                                         H.stream()), "fcmf_add_ln_bwd")
