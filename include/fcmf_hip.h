@@ -65,6 +65,9 @@ int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* au
 /* tuning hook for benchmarks/tests: 0 = built-in heuristic; 128 = 128x128 kernel, 256 / 192 = persistent
  * 256x256 / 192x256 kernel wherever its preconditions hold */
 void fcmf_gemm_force_tile(int tile);
+/* 32: keep the 32-deep k-tile kernels everywhere; anything else: 64-deep k-tiles where they apply (the default).  The two
+ * depths issue the same MFMAs in the same order: results are bit-identical (tests rely on that). */
+void fcmf_gemm_force_kb(int kb);
 
 /* Optional caller-owned scratch for split-K weight-gradient GEMMs issued on `stream`: with at least
  * ksplit*M*N*4 bytes registered the k-split partial tiles are written with plain stores and summed by a reduce

@@ -1222,10 +1222,12 @@ static thread_local char g_last_kernel[96] = "";
 extern "C" const char* fcmf_gemm_last_kernel(void) { return g_last_kernel; }
 static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced kernel (benchmarks, tests)
 extern "C" void fcmf_gemm_force_tile(int tile) { g_force_tile = tile; }
-// FCMF_GEMM_KB=32 (read once) keeps the 32-deep k-tiles everywhere (A/B measurements of the 64-deep variant)
 // bf16 outputs of at least this many bytes leave the persistent kernels with nontemporal stores (FCMF_GEMM_NT_MIN_MB, read once)
 static int64_t g_nt_min_bytes = [] { const char* e = getenv("FCMF_GEMM_NT_MIN_MB"); return (int64_t)(e ? atoi(e) : 0) << 20; }();
+// FCMF_GEMM_KB=32 (read once) keeps the 32-deep k-tiles everywhere (A/B measurements of the 64-deep variant);
+// fcmf_gemm_force_kb(32) does the same at run time (tests: both depths multiply in the same order -> identical bits)
 static int g_kb64 = [] { const char* e = getenv("FCMF_GEMM_KB"); return !(e && atoi(e) == 32); }();
+extern "C" void fcmf_gemm_force_kb(int kb) { g_kb64 = kb != 32; }
 
 extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum, int M,
                          int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,

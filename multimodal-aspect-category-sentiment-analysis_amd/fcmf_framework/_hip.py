@@ -37,6 +37,7 @@ SIGNATURES = {
     "fcmf_build_info": [],
     "fcmf_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_gemm_force_tile": [_i],
+    "fcmf_gemm_force_kb": [_i],
     "fcmf_gemm_last_kernel": [],
     "fcmf_gemm_set_workspace": [_vp, _i64, _vp],
     "fcmf_colsum": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
@@ -102,7 +103,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = (ctypes.c_char_p if name in ("fcmf_build_info", "fcmf_gemm_last_kernel") else
-                          None if name == "fcmf_gemm_force_tile" else
+                          None if name in ("fcmf_gemm_force_tile", "fcmf_gemm_force_kb") else
                           ctypes.c_int64 if name in ("fcmf_add_ln_bwd_workspace", "fcmf_bn_stats_workspace") else ctypes.c_int)
         _lib = l
     return _lib

@@ -67,6 +67,40 @@ def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
     assert rel_err(Cf, Af @ Bf + 0.5) < 1e-3
 
 
+@pytest.mark.parametrize("epi", ["none", "gelu", "dgelu", "add"])
+@pytest.mark.parametrize("M,N,K", [(1000, 776, 320), (4400, 4104, 128), (6144, 768, 768)])
+def test_gemm_k64_and_k32_kernels_agree_bitwise(dev, M, N, K, epi):
+    """the 64-deep k-tile kernels (whole-line DMA, five-slot ring) issue the same MFMAs in the same order as the 32-deep
+    ones: every output bit must agree, for every epilogue"""
+    ops, H = _ops()
+    A, B = _rand((M, K), dev, torch.bfloat16, seed=1), _rand((N, K), dev, torch.bfloat16, 0.2, seed=2)
+    bias = _rand((N,), dev, seed=3)
+    u = _rand((M, N), dev, torch.bfloat16, 1.5, seed=5)
+    outs = []
+    for kb in (32, 64):
+        H.lib().fcmf_gemm_force_kb(kb)
+        H.lib().fcmf_gemm_force_tile(256)          # the persistent kernels also for the small ragged case
+        try:
+            C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            aux = torch.empty_like(C)
+            if epi == "none":
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias)
+            elif epi == "gelu":
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, aux=aux, epi=H.EPI_GELU)
+            elif epi == "dgelu":
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, aux=u, epi=H.EPI_DGELU)
+            else:
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, aux=u, epi=H.EPI_ADD)
+            outs.append((C.clone(), aux.clone() if epi == "gelu" else None, H.lib().fcmf_gemm_last_kernel().decode()))
+        finally:
+            H.lib().fcmf_gemm_force_kb(64)
+            H.lib().fcmf_gemm_force_tile(0)
+    assert "k64" not in outs[0][2] and "k64" in outs[1][2], (outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][0], outs[1][0])
+    if epi == "gelu":
+        assert torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("M,N,K,nk_note", [(700, 520, 96, "3 k-tiles"), (4400, 4104, 64, "306 tiles: two rounds of work items per CU"),
                                            (300, 264, 32, "1 k-tile"), (1100, 776, 160, "5 k-tiles"),
                                            (1100, 776, 192, "3 k-tiles of 64"), (4400, 4104, 128, "2 k-tiles of 64, two rounds"),
