@@ -166,6 +166,22 @@ template <int NKT>
 __device__ __forceinline__ void attn_mfma_fwd_tile(const AttnMfmaParams& P, int g, int h, int q0, int lane, const bf16x8 (&qf)[2][2],
                                                    const char* Ks, const char* Vs, const float* mask_lds = nullptr) {
   constexpr int NKF = 8 * NKT;       // 16-key fragments
+  const float* mrow = P.mask ? P.mask + (int64_t)g * P.Tk : nullptr;
+  // trailing keys under the "hard" additive mask (<= -1e30: HF's finfo.min padding mask) get probabilities that are EXACTLY
+  // zero: their 16-key fragments (scores, softmax terms, P V steps) are skipped with bit-identical results.
+  // nvalid = index of the last key that is not hard-masked, + 1 (wave-uniform).
+  int nvalid = P.Tk;
+  if (mask_lds || mrow) {
+    int last = -1;
+#pragma unroll
+    for (int i = 0; i < 2 * NKT; ++i) {
+      const int key = 64 * i + lane;
+      const bool live = key < P.Tk && (mask_lds ? mask_lds[key] : mrow[key]) > -1e30f;
+      const unsigned long long b = __ballot(live);
+      if (b) last = 64 * i + 63 - __builtin_clzll(b);
+    }
+    nvalid = last + 1 > 0 ? last + 1 : 1;
+  }
   // S^T[key][q]: NKF key fragments x 2 query fragments
   f32x4 sc[NKF][2];
 #pragma unroll
@@ -176,19 +192,20 @@ __device__ __forceinline__ void attn_mfma_fwd_tile(const AttnMfmaParams& P, int 
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int kf = 0; kf < NKF; ++kf) {
+      if (16 * kf >= nvalid) continue;
       const bf16x8 ka = frag_row64(Ks, 16 * kf, s, lane);
 #pragma unroll
       for (int f = 0; f < 2; ++f) sc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[f][s], sc[kf][f], 0, 0, 0);
     }
   // lane holds, for query q0+16f+(lane&15), keys 16kf + 4(lane>>4) + r
   const float inv_keep = P.p > 0.f ? 1.0f / (1.0f - P.p) : 1.0f;
-  const float* mrow = P.mask ? P.mask + (int64_t)g * P.Tk : nullptr;
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int q = q0 + 16 * f + (lane & 15);
     float m = -INFINITY;
 #pragma unroll
-    for (int kf = 0; kf < NKF; ++kf)
+    for (int kf = 0; kf < NKF; ++kf) {
+      if (16 * kf >= nvalid) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * kf + 4 * (lane >> 4) + r;
@@ -197,23 +214,27 @@ __device__ __forceinline__ void attn_mfma_fwd_tile(const AttnMfmaParams& P, int 
         sc[kf][f][r] = s;
         m = fmaxf(m, s);
       }
+    }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int kf = 0; kf < NKF; ++kf)
+    for (int kf = 0; kf < NKF; ++kf) {
+      if (16 * kf >= nvalid) continue;         // (sc of a skipped fragment stays 0 = its probabilities)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __expf(sc[kf][f][r] - m);
         sc[kf][f][r] = e;
         sum += e;
       }
+    }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (q < P.Tq && (lane >> 4) == 0 && P.lse) P.lse[((int64_t)g * P.heads + h) * P.Tq + q] = m + __logf(sum);
 #pragma unroll
     for (int kf = 0; kf < NKF; ++kf) {
+      if (16 * kf >= nvalid) continue;
       float dm[4] = {1.f, 1.f, 1.f, 1.f};
       if (P.p > 0.f)
         dropout_mult4(P.seed, ((uint64_t)g * P.heads + h) * P.Tq * P.Tk + (__umul24((unsigned)q, (unsigned)P.Tk) + (unsigned)(16 * kf + 4 * (lane >> 4))),
@@ -230,6 +251,7 @@ __device__ __forceinline__ void attn_mfma_fwd_tile(const AttnMfmaParams& P, int 
     for (int f = 0; f < 2; ++f) oc[df][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 4 * NKT; ++s) {
+    if (32 * s >= nvalid) continue;
     // P^T operand of k-step s straight from the accumulators of key fragments 2s and 2s+1
     bf16x8 pb[2];
 #pragma unroll
@@ -446,7 +468,23 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
   // ---- key chunks of 32; per chunk the query tiles take turns: phase 1 (wave = 32 query rows) builds Pdrop^T and dS^T
   // [key][q] of (chunk, query tile) in LDS, phase 2 adds them to dQ of that tile (wave = 32 queries) and to dV / dK of
   // the chunk's 32 keys (wave = 16 columns), which are stored after the last query tile
-  const int nchunks = (P.Tk + 31) >> 5;
+  const int nchunks_all = (P.Tk + 31) >> 5;
+  // trailing keys whose additive mask is the "hard" value (<= -1e30: HF's finfo.min padding mask) have probabilities that
+  // are EXACTLY zero (exp underflows), so whole 32-key chunks of them contribute nothing to dQ and get dK = dV = 0: they
+  // are skipped, with bit-identical results.  nvalid = index of the last key that is not hard-masked, + 1 (wave-uniform).
+  int nvalid = P.Tk;
+  if (mrow) {
+    int last = -1;
+#pragma unroll
+    for (int i = 0; i < 2 * NKT; ++i) {
+      const int key = 64 * i + lane;
+      const bool live = key < P.Tk && mrow[key] > -1e30f;
+      const unsigned long long b = __ballot(live);
+      if (b) last = 64 * i + 63 - __builtin_clzll(b);
+    }
+    nvalid = last + 1 > 0 ? last + 1 : 1;
+  }
+  const int nchunks = (nvalid + 31) >> 5;
   f32x4 cV = f32x4{0.f, 0.f, 0.f, 0.f}, cK = f32x4{0.f, 0.f, 0.f, 0.f};   // column sums of dV / dK over the keys (this lane's keys)
   for (int c = 0; c < nchunks; ++c) {
     f32x4 aV[2], aK[2];
@@ -531,6 +569,17 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
         f32x4 t = aK[kf];
         t[0] *= P.scale; t[1] *= P.scale; t[2] *= P.scale; t[3] *= P.scale;
         store4(P.dk + (kbase + key) * P.ldk + dcol, t);
+      }
+    }
+  }
+  for (int c = nchunks; c < nchunks_all; ++c) {      // the skipped (fully hard-masked) chunks: dK = dV = 0
+    const int dcol = h * AD + 16 * w + 4 * (lane >> 4);
+#pragma unroll
+    for (int kf = 0; kf < 2; ++kf) {
+      const int key = 32 * c + 16 * kf + (lane & 15);
+      if (key < P.Tk) {
+        store4(P.dv + (kbase + key) * P.ldk + dcol, f32x4{0.f, 0.f, 0.f, 0.f});
+        store4(P.dk + (kbase + key) * P.ldk + dcol, f32x4{0.f, 0.f, 0.f, 0.f});
       }
     }
   }

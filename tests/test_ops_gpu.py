@@ -723,6 +723,42 @@ def test_attention_mfma_backward_column_sums(dev, T, p):
     assert (bg - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("T", [128, 256, 100])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attention_mfma_padded_sequences_skip_is_exact(dev, T, p):
+    """padding = a hard-masked (finfo.min) key suffix: the MFMA kernels skip the fully masked trailing key fragments /
+    chunks.  Results must equal the VALU kernel's (same dropout seed) on every valid row, dk / dv of the padded keys must be
+    exactly zero, and lengths 1 .. T (incl. chunk boundaries) must all work."""
+    from fcmf_framework import ops
+    heads, d = 2, 64
+    HD = heads * d
+    lens = [1, 5, 16, 17, 31, 32, 33, 63, 64, 65, 96, 97, T - 1, T]
+    lens = [min(l, T) for l in lens]
+    G = len(lens)
+    mk = lambda shape, s: _rand(shape, dev, torch.bfloat16, 0.8, seed=s)
+    q0, k0, v0 = mk((G, T, HD), 1), mk((G, T, HD), 2), mk((G, T, HD), 3)
+    m01 = torch.zeros(G, T)
+    for g, l in enumerate(lens):
+        m01[g, :l] = 1
+    mask = ((1 - m01) * torch.finfo(torch.float32).min).to(dev)
+    w = mk((G, T, HD), 9)
+    res = {}
+    for use in (True, False):
+        ops.USE_MFMA_ATTENTION = use
+        try:
+            q, k, v = (t.clone().requires_grad_(True) for t in (q0, k0, v0))
+            ops.manual_seed(5)
+            out = ops.attention(q, k, v, mask=mask, heads=heads, p=p, training=p > 0)
+            (out.float() * w.float()).sum().backward()
+            res[use] = (out.detach(), q.grad, k.grad, v.grad)
+        finally:
+            ops.USE_MFMA_ATTENTION = True
+    for a, b, name in zip(res[True], res[False], ("out", "dq", "dk", "dv")):
+        assert rel_err(a, b) < 3e-2, name
+    for g, l in enumerate(lens):           # padded keys receive exactly zero gradient
+        assert not res[True][2][g, l:].any() and not res[True][3][g, l:].any()
+
+
 @pytest.mark.parametrize("Tq,Tk", [(128, 128), (77, 128), (128, 50), (33, 17), (256, 256), (200, 256), (256, 150), (130, 129)])
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_attention_mfma_matches_reference_and_valu_kernel(dev, Tq, Tk, p):
