@@ -607,6 +607,183 @@ __global__ __launch_bounds__(256) void attn_private_grad_kernel(AttnK P) {
   }
 }
 
+// =========================================================================================================================
+// "Tiny dense" attention: one shared key segment of <= 64 keys, <= 64 query rows, bf16, no causal fill (the geometry-biased
+// ROI attention: 36 x 36, 8 heads of 96; 4 us of arithmetic per (group, head)).  The general kernels above walk the query
+// rows one wave at a time (9 rounds of dependent LDS / reduction latencies here); with everything in LDS this one is a few
+// flat, fully parallel loops: thread = (row, key) for the scores, wave = row for the softmax, thread = (row, column) for the
+// outputs.  Same arithmetic, same dropout counters, same outputs as the general kernels.
+// =========================================================================================================================
+constexpr int TINY_MAX = 64;
+
+__device__ __forceinline__ float dot_bf16_lds(const bf16_t* a, const bf16_t* b, int d) {      // d % 8 == 0, 16-byte aligned rows
+  // v_dot2c_f32_bf16: two bf16 products added to an f32 accumulator per instruction, no conversions (two interleaved
+  // accumulation chains)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  float s0 = 0.f, s1 = 0.f;
+  for (int c = 0; c < d; c += 8) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + c), y = *reinterpret_cast<const bf16x8*>(b + c);
+    s0 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{x[0], x[1]}, bf16x2_t{y[0], y[1]}, s0, false);
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{x[2], x[3]}, bf16x2_t{y[2], y[3]}, s1, false);
+    s0 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{x[4], x[5]}, bf16x2_t{y[4], y[5]}, s0, false);
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{x[6], x[7]}, bf16x2_t{y[6], y[7]}, s1, false);
+  }
+  return s0 + s1;
+}
+
+__global__ __launch_bounds__(256) void attn_tiny_fwd_kernel(AttnK P) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const fcmf_attn_desc& a = P.a;
+  const int d = a.d, T = a.T1, R = a.R, dp = d + 8, TP = T + 1;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(sm);
+  bf16_t* Ks = Qs + R * dp;
+  bf16_t* Vs = Ks + T * dp;
+  float* Ss = reinterpret_cast<float*>(Vs + T * dp);     // [R][TP]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = blockIdx.x / a.heads, h = blockIdx.x % a.heads, g2 = g / a.group_div;
+  stage_rows<bf16_t, bf16_t>(Qs, dp, reinterpret_cast<const bf16_t*>(a.q) + (int64_t)g * a.q_sg + h * d, a.q_sr, R, d, w, lane);
+  stage_rows<bf16_t, bf16_t>(Ks, dp, reinterpret_cast<const bf16_t*>(a.k1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T, d, w, lane);
+  stage_rows<bf16_t, bf16_t>(Vs, dp, reinterpret_cast<const bf16_t*>(a.v1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T, d, w, lane);
+  // additive terms (bias tile + key mask) staged with the operands: one coalesced pass, all loads in flight together (a
+  // global load per score inside the loop below serialises on its latency)
+  for (int idx = tid; idx < R * T; idx += 256) {
+    const int r = idx / T, t = idx - r * T;
+    float add = 0.f;
+    if (a.mask) add = a.mask[(int64_t)g * T + t];
+    if (a.bias) add += a.bias[(((int64_t)g2 * a.heads + h) * R) * T + idx];
+    Ss[r * TP + t] = add;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < R * T; idx += 256) {
+    const int r = idx / T, t = idx - r * T;
+    Ss[r * TP + t] += dot_bf16_lds(Qs + r * dp, Ks + t * dp, d) * a.scale;      // (the same thread staged this element)
+  }
+  __syncthreads();
+  const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  for (int r = w; r < R; r += 4) {
+    const float s = lane < T ? Ss[r * TP + lane] : -INFINITY;
+    const float m = wave_max(s);
+    const float e = lane < T ? __expf(s - m) : 0.f;
+    const float sum = wave_sum(e);
+    if (lane < T) {
+      float pv = e / sum;
+      if (a.dropout_p > 0.f) pv *= dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + lane, a.dropout_p, inv_keep);
+      Ss[r * TP + lane] = pv;
+    }
+    if (lane == 0 && P.lse) P.lse[((int64_t)g * a.heads + h) * R + r] = m + __logf(sum);
+  }
+  __syncthreads();
+  bf16_t* O = reinterpret_cast<bf16_t*>(P.out);
+  const int d8 = d >> 3;
+  for (int idx = tid; idx < R * d8; idx += 256) {        // thread = (row, 8 columns): one 16-byte V read per key
+    const int r = idx / d8, c = (idx - r * d8) * 8;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) {
+      const float pv = Ss[r * TP + t];
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(Vs + t * dp + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += pv * (float)v[j];
+    }
+    bf16x8 ov;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)o[j];
+    *reinterpret_cast<bf16x8*>(O + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d + c) = ov;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_tiny_bwd_kernel(AttnK P) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const fcmf_attn_desc& a = P.a;
+  const int d = a.d, T = a.T1, R = a.R, dp = d + 8, TP = T + 1;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(sm);
+  bf16_t* dOs = Qs + R * dp;
+  bf16_t* Ks = dOs + R * dp;
+  bf16_t* Vs = Ks + T * dp;
+  float* PD = reinterpret_cast<float*>(Vs + T * dp);     // [R][TP] dropped probabilities
+  float* DS = PD + R * TP;                               // [R][TP] score gradients
+  float* dl = DS + R * TP;                               // [R] delta = <dO, O>
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = blockIdx.x / a.heads, h = blockIdx.x % a.heads, g2 = g / a.group_div;
+  const int64_t HD = (int64_t)a.heads * d;
+  const bf16_t* dO = reinterpret_cast<const bf16_t*>(P.dout);
+  const bf16_t* O = reinterpret_cast<const bf16_t*>(P.o_in);
+  stage_rows<bf16_t, bf16_t>(Qs, dp, reinterpret_cast<const bf16_t*>(a.q) + (int64_t)g * a.q_sg + h * d, a.q_sr, R, d, w, lane);
+  stage_rows<bf16_t, bf16_t>(dOs, dp, dO + (int64_t)g * a.o_sg + h * d, a.o_sr, R, d, w, lane);
+  stage_rows<bf16_t, bf16_t>(Ks, dp, reinterpret_cast<const bf16_t*>(a.k1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T, d, w, lane);
+  stage_rows<bf16_t, bf16_t>(Vs, dp, reinterpret_cast<const bf16_t*>(a.v1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T, d, w, lane);
+  for (int idx = tid; idx < R * T; idx += 256) {         // additive terms staged up front (see the forward kernel)
+    const int r = idx / T, t = idx - r * T;
+    float add = 0.f;
+    if (a.mask) add = a.mask[(int64_t)g * T + t];
+    if (a.bias) add += a.bias[(((int64_t)g2 * a.heads + h) * R) * T + idx];
+    DS[r * TP + t] = add - P.lse[((int64_t)g * a.heads + h) * R + r];      // score offset: + mask + bias - logsumexp
+  }
+  for (int r = w; r < R; r += 4) {                       // delta[r] straight from global memory (dO, O rows)
+    const bf16_t* orow = O + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
+    const bf16_t* drow = dO + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
+    float part = 0.f;
+    for (int c = lane; c < d; c += 64) part += (float)drow[c] * (float)orow[c];
+    part = wave_sum(part);
+    if (lane == 0) dl[r] = part;
+  }
+  __syncthreads();
+  const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  for (int idx = tid; idx < R * T; idx += 256) {
+    const int r = idx / T, t = idx - r * T;
+    const float s = dot_bf16_lds(Qs + r * dp, Ks + t * dp, d) * a.scale;
+    const float dpd = dot_bf16_lds(dOs + r * dp, Vs + t * dp, d);
+    const float pr = __expf(s + DS[r * TP + t]);          // (staged by this same thread: + mask + bias - logsumexp)
+    float mult = 1.0f;
+    if (a.dropout_p > 0.f) mult = dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + t, a.dropout_p, inv_keep);
+    const float dsv = pr * (dpd * mult - dl[r]);
+    PD[r * TP + t] = pr * mult;
+    DS[r * TP + t] = dsv;
+    if (P.dbias) P.dbias[(((int64_t)g * a.heads + h) * R + r) * T + t] = dsv;
+  }
+  __syncthreads();
+  bf16_t* dQ = reinterpret_cast<bf16_t*>(P.dq);
+  bf16_t* dK = reinterpret_cast<bf16_t*>(P.dk1);
+  bf16_t* dV = reinterpret_cast<bf16_t*>(P.dv1);
+  const int d8 = d >> 3;
+  for (int idx = tid; idx < R * d8; idx += 256) {        // thread = (row, 8 columns)
+    const int r = idx / d8, c = (idx - r * d8) * 8;
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) {
+      const float dsv = DS[r * TP + t];
+      const bf16x8 kk = *reinterpret_cast<const bf16x8*>(Ks + t * dp + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] += dsv * (float)kk[j];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(q[j] * a.scale);
+    *reinterpret_cast<bf16x8*>(dQ + ((int64_t)g * R + r) * HD + h * d + c) = o;
+  }
+  for (int idx = tid; idx < T * d8; idx += 256) {        // thread = (key, 8 columns)
+    const int t = idx / d8, c = (idx - t * d8) * 8;
+    float k[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r) {
+      const float dsv = DS[r * TP + t], pv = PD[r * TP + t];
+      const bf16x8 qq = *reinterpret_cast<const bf16x8*>(Qs + r * dp + c), gg = *reinterpret_cast<const bf16x8*>(dOs + r * dp + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { k[j] += dsv * (float)qq[j]; v[j] += pv * (float)gg[j]; }
+    }
+    bf16x8 ok, ov;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ok[j] = (bf16_t)(k[j] * a.scale); ov[j] = (bf16_t)v[j]; }
+    *reinterpret_cast<bf16x8*>(dK + ((int64_t)g * T + t) * HD + h * d + c) = ok;
+    *reinterpret_cast<bf16x8*>(dV + ((int64_t)g * T + t) * HD + h * d + c) = ov;
+  }
+}
+
+// the tiny kernels' preconditions (host)
+static bool tiny_ok(const fcmf_attn_desc* a) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return a->dtype == FCMF_BF16 && a->T2 == 0 && a->T1 > 0 && a->T1 <= TINY_MAX && a->R <= TINY_MAX && !a->causal && !a->head_quirk &&
+         a->d % 8 == 0 && a->q_sr % 8 == 0 && a->q_sg % 8 == 0 && a->k1_st % 8 == 0 && a->k1_sg % 8 == 0 && a->o_sr % 8 == 0 &&
+         a->o_sg % 8 == 0 && al16(a->q) && al16(a->k1) && al16(a->v1);      // (+ 16-byte aligned outputs: checked by the callers)
+}
+
 static int check_desc(const fcmf_attn_desc* a) {
   if (!a || !a->q) return FCMF_ERR_ARG;
   if (a->dtype != FCMF_F32 && a->dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
@@ -635,6 +812,14 @@ extern "C" int fcmf_attn_small_fwd(const fcmf_attn_desc* desc, void* out, float*
   if (!out) return FCMF_ERR_ARG;
   AttnK P{};
   P.a = *desc; P.out = out; P.lse = lse;
+  if (tiny_ok(desc) && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int dp = desc->d + 8;
+    const size_t smem = (size_t)(desc->R + 2 * desc->T1) * dp * 2 + sizeof(float) * (size_t)desc->R * (desc->T1 + 1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_tiny_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(attn_tiny_fwd_kernel, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+    FCMF_CHECK_LAUNCH();
+    return FCMF_OK;
+  }
   const size_t esz = desc->dtype == FCMF_F32 ? 4 : 2;
   P.KVF = (int)((2 * (size_t)desc->T1 * (desc->d + 16 / esz) * esz + 15) / 16 * 4);   // K and V images, rounded to 16 B, in floats
   const int kpl = desc->T1 + desc->T2 <= 256 ? 4 : 8;     // keys per lane of the forward
@@ -684,6 +869,17 @@ static int attn_small_bwd_impl(const fcmf_attn_desc* desc, const void* out, cons
       return FCMF_ERR_UNSUPPORTED;
     if (scratch_bytes < 2 * n2 * (int64_t)sizeof(float)) return FCMF_ERR_ARG;
     P.pd2 = scratch; P.ds2 = scratch + n2;
+  }
+  if (!grouped && dv1 && tiny_ok(desc) &&
+      ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) |
+        reinterpret_cast<uintptr_t>(dk1) | reinterpret_cast<uintptr_t>(dv1)) & 15) == 0) {
+    const int dp = desc->d + 8;
+    const size_t smem = (size_t)(2 * desc->R + 2 * desc->T1) * dp * 2 +
+                        sizeof(float) * ((size_t)2 * desc->R * (desc->T1 + 1) + desc->R);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_tiny_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(attn_tiny_bwd_kernel, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+    FCMF_CHECK_LAUNCH();
+    return FCMF_OK;
   }
   const int nsh = desc->T1 < 128 ? desc->T1 : 128;
   const size_t esz = desc->dtype == FCMF_F32 ? 4 : 2;

@@ -344,6 +344,10 @@ ATTN_CASES = [
     (12, 7, 3, 64, 0, 49, 6, True, False, False),     # the step's text->patch cross attention: private keys only, 6 aspects per review
     (6, 5, 2, 64, 40, 70, 3, True, False, False),     # > 64 private keys: three rounds of the 16-byte private-key walk
     (16, 3, 2, 16, 10, 7, 16, True, False, False),    # group of 16 > 8: per-group rows + host-side sum (ungrouped fallback)
+    (4, 36, 8, 96, 36, 0, 1, False, True, False),     # the step's ROI box attention (bf16: the all-in-LDS "tiny dense" kernels)
+    (4, 36, 8, 96, 36, 0, 2, True, True, False),      # the same with a key mask and a bias shared by groups of 2
+    (2, 64, 2, 64, 64, 0, 1, True, False, False),     # the tiny kernels' limits: 64 rows x 64 keys
+    (2, 65, 2, 64, 64, 0, 1, True, False, False),     # one row more: back on the general kernel
 ]
 
 
@@ -380,6 +384,25 @@ def test_attention_fwd_bwd(dev, dtype, case):
                        ("dbias", bias, br)):
         if a is not None:
             assert rel_err(a.grad, b.grad) < tol * 2, name
+
+
+def test_attention_tiny_dropout_consistent(dev):
+    """the all-in-LDS kernels (bf16, <= 64 rows / keys): with V = I the output IS the dropped probability matrix; kept entries
+    are the plain probabilities / (1 - p), and the backward uses the same mask (dV = P_drop^T dO)."""
+    ops, H = _ops()
+    G, R, T, p = 6, 16, 16, 0.3
+    q = _rand((G, R, T), dev, torch.bfloat16, seed=1)
+    k = _rand((G, T, T), dev, torch.bfloat16, seed=2)
+    v = torch.eye(T, device=dev, dtype=torch.bfloat16).expand(G, T, T).contiguous().requires_grad_(True)
+    ops.manual_seed(321)
+    out = ops.attention(q, k, v, heads=1, p=p, training=True)
+    plain = ops.attention(q, k, v, heads=1, p=0.0, training=False)
+    pdrop, pfull = out.detach().float(), plain.detach().float()
+    kept = pdrop != 0
+    assert 0.55 < kept.float().mean().item() < 0.85
+    assert torch.allclose(pdrop[kept], pfull[kept] / (1 - p), rtol=2e-2, atol=1e-3)
+    out.sum().backward()                       # dO = 1: dV[t][c] = sum_r P_drop[r][t] for every column c
+    assert torch.allclose(v.grad.float()[:, :, 0], pdrop.sum(1), rtol=2e-2, atol=2e-2)
 
 
 def test_attention_dropout_consistent(dev):
