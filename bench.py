@@ -215,7 +215,7 @@ def run_fcmf(args, rank, world, dev, large=False):
     if world > 1 or not args.no_arena:
         arena = GradArena.for_model(model)     # as run_multimodal_fcmf.py does (leaves out bert.cell.pooler: it never gets a gradient)
         if world > 1:
-            red = GradReducer(arena)
+            red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native)
             red.broadcast_parameters(0)
     host = synth.synth_batch(B, CFG, S=S, num_imgs=NI, num_roi=NR, num_aspects=A, seed=42 + rank)
     batch = {k: v.to(dev) for k, v in host.items()}
@@ -302,7 +302,7 @@ def run_iaog(args, rank, world, dev):
     arena = GradArena.for_model(model)      # one memset per step instead of a zero fill per weight gradient
     red = None
     if world > 1:
-        red = GradReducer(arena)
+        red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native)
         red.broadcast_parameters(0)
     b = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, num_aspects=1, seed=3 + rank, coord_dtype=torch.float32)
     b = {k: v.to(dev) for k, v in b.items()}
@@ -387,6 +387,10 @@ def main():
     ap.add_argument("--no-arena", dest="no_arena", action="store_true",
                     help="single GPU: per-weight gradient tensors instead of the flat gradient arena the drivers use (always on for --gpus > 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--dp-exchange", dest="dp_exchange", default="fp32", choices=["fp32", "bf16"],
+                    help="gradient exchange: float32 all-reduce in place (default, DDP-comparable) or bf16 on the links with float32 accumulation")
+    ap.add_argument("--dp-native", dest="dp_native", action="store_true",
+                    help="all-reduce through the library's own RCCL binding (fcmf_dp_allreduce_bucket) instead of torch.distributed")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))

@@ -26,6 +26,7 @@ extern "C" {
 #define FCMF_ERR_ARG (-1)
 #define FCMF_ERR_LAUNCH (-2)
 #define FCMF_ERR_UNSUPPORTED (-3)
+#define FCMF_ERR_COMM (-4)        /* RCCL unavailable or a collective call failed */
 
 #define FCMF_F32 0
 #define FCMF_BF16 1
@@ -329,6 +330,23 @@ int fcmf_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H,
 /* F.adaptive_avg_pool2d backward: dy float32 in the forward's output layout (0 = [N,C,oh,ow], 1 = [N,oh*ow,C]) */
 int fcmf_adaptive_avgpool_bwd(const float* dy, void* dx, int N, int H, int W, int C, int oh, int ow, int layout,
                               int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (reference: torch.distributed.init_process_group("nccl") + DistributedDataParallel,
+ * run_multimodal_fcmf.py:169,237-240; run_pretraining_fcmf.py:196-199).  One communicator per process (= per GPU, the HIP
+ * device current at creation time); the flat gradient arena is all-reduced bucket by bucket IN PLACE on `stream`
+ * (RCCL over xGMI), so the collective of one bucket overlaps the backward kernels that are still producing the next.
+ * RCCL is bound at run time (the process's own copy if it has one, e.g. PyTorch's): FCMF_ERR_COMM when it is absent.
+ *   fcmf_dp_unique_id   : rank 0 fills a HOST buffer of FCMF_DP_UNIQUE_ID_BYTES and hands it to the other ranks out of band
+ *                         (the drivers use their torch.distributed store);
+ *   fcmf_dp_comm_create : collective over the `nranks` processes holding that id; *comm receives an opaque handle;
+ *   fcmf_dp_allreduce_bucket: buf[count] of `dtype` (FCMF_F32 / FCMF_BF16) <- sum (average = 0) or mean (average != 0, formed
+ *                         inside the collective) over the ranks; enqueued on `stream`, returns at once. */
+#define FCMF_DP_UNIQUE_ID_BYTES 128
+int fcmf_dp_unique_id(void* out_host);
+int fcmf_dp_comm_create(void** comm, const void* unique_id_host, int nranks, int rank);
+int fcmf_dp_comm_destroy(void* comm);
+int fcmf_dp_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype, int average, void* stream);
 
 #ifdef __cplusplus
 }

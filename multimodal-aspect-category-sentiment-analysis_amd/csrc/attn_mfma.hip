@@ -180,7 +180,7 @@ __device__ __forceinline__ void attn_mfma_fwd_tile(const AttnMfmaParams& P, int 
       const unsigned long long b = __ballot(live);
       if (b) last = 64 * i + 63 - __builtin_clzll(b);
     }
-    nvalid = last + 1 > 0 ? last + 1 : 1;
+    nvalid = last >= 0 ? last + 1 : P.Tk;    // no live key at all: nothing may be skipped (softmax over finfo.min scores is uniform over ALL keys)
   }
   // S^T[key][q]: NKF key fragments x 2 query fragments
   f32x4 sc[NKF][2];
@@ -482,7 +482,7 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
       const unsigned long long b = __ballot(live);
       if (b) last = 64 * i + 63 - __builtin_clzll(b);
     }
-    nvalid = last + 1 > 0 ? last + 1 : 1;
+    nvalid = last >= 0 ? last + 1 : P.Tk;    // no live key at all: nothing may be skipped (softmax over finfo.min scores is uniform over ALL keys)
   }
   const int nchunks = (nvalid + 31) >> 5;
   f32x4 cV = f32x4{0.f, 0.f, 0.f, 0.f}, cK = f32x4{0.f, 0.f, 0.f, 0.f};   // column sums of dV / dK over the keys (this lane's keys)

@@ -80,6 +80,10 @@ SIGNATURES = {
     "fcmf_bn_apply": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _vp],
     "fcmf_maxpool3x3s2": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "fcmf_adaptive_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_dp_unique_id": [_vp],
+    "fcmf_dp_comm_create": [_c.POINTER(_vp), _vp, _i, _i],
+    "fcmf_dp_comm_destroy": [_vp],
+    "fcmf_dp_allreduce_bucket": [_vp, _vp, _i64, _i, _i, _vp],
 }
 
 _lib = None
@@ -109,7 +113,8 @@ def lib():
     return _lib
 
 
-_ERR = {-1: "bad argument", -2: "kernel launch failed", -3: "unsupported configuration"}
+_ERR = {-1: "bad argument", -2: "kernel launch failed", -3: "unsupported configuration",
+        -4: "RCCL unavailable or collective failed"}
 
 
 def check(rc, what):

@@ -45,10 +45,13 @@ class GradArena:
                     order.append(q)
         self.order = order
         self.offset, off = {}, 0
+        self.packed = set()                   # parameters packed tight behind their block head (no alignment gap before them)
         for p in order:
             adj = id(p) in in_block and blocks[in_block[id(p)]][0] is not p      # packed tight behind its block head
             if not adj:
                 off = (off + ALIGN - 1) // ALIGN * ALIGN
+            else:
+                self.packed.add(id(p))
             self.offset[id(p)] = off
             off += p.numel()
         self.total = (off + ALIGN - 1) // ALIGN * ALIGN
@@ -96,7 +99,9 @@ class GradArena:
         """the slice of `param` if nothing has claimed it in this step (else None: the caller uses a temporary and
         autograd accumulates it into the slice in place)"""
         p = self._by_ptr.get(param.data_ptr())
-        if p is None or id(p) in self._taken or p.grad is not None:
+        # (matched by address: a [3H, H] view of the fused q|k|v block shares the query weight's pointer -- the element
+        #  count tells them apart; blocks go through take_block)
+        if p is None or p.numel() != param.numel() or id(p) in self._taken or p.grad is not None:
             return None
         self._taken.add(id(p))
         return self.view[id(p)]
@@ -128,41 +133,87 @@ class GradArena:
 
 
 class GradReducer:
-    def __init__(self, arena, bucket_mb=128, process_group=None, overlap=True):
+    """bucketed in-place gradient mean over the ranks, overlapped with backward.
+
+    bucket_mb : target bucket size.  32 MB by default: xGMI is point to point (7 links x ~150 GB/s per GPU), a ring
+                all-reduce is bound by one link, and a bucket must be large enough to amortise the collective's launch +
+                synchronisation (~20-30 us) yet small enough that the first collective starts early in backward and the
+                LAST one -- the only one nothing can hide -- is short.  FCMF-base: 626 MB of float32 gradients = 20 buckets.
+    exchange  : "fp32" -- all-reduce of the float32 slices in place (bit-comparable with DDP);
+                "bf16" -- half the bytes on the links with float32 ACCUMULATION on arrival: each rank sends shard j of its
+                bucket, rounded to bf16, to rank j (all-to-all), rank j sums the `world` shards in float32, rounds the sum to
+                bf16 once and all-gathers it.  (A bf16 all-reduce would round the running sum at every ring step.)  Every
+                rank ends up with the same bits, so replicas cannot drift.
+    native    : all-reduce through the C ABI (`fcmf_dp_allreduce_bucket`: RCCL bound by libfcmf_hip.so itself) instead of
+                `torch.distributed.all_reduce`; fp32 exchange, CUDA tensors, one GPU per process.
+    recheck_every: how often (in optimizer steps) the set of parameters that receive no gradient on any rank is
+                re-verified -- a parameter that turns live on SOME rank later raises on EVERY rank instead of
+                silently diverging replicas (round-2 advisor finding)."""
+
+    def __init__(self, arena, bucket_mb=32, process_group=None, overlap=True, exchange="fp32", native=False, recheck_every=50):
         if not isinstance(arena, GradArena):                      # list of parameters (round-1 signature)
             arena = GradArena(list(arena))
+        if exchange not in ("fp32", "bf16"):
+            raise ValueError("exchange must be 'fp32' or 'bf16'")
         self.arena = arena
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.params = arena.order
         self.overlap = overlap
+        self.exchange = exchange
+        self.recheck_every = recheck_every
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets = []                     # (lo, hi, [params]) contiguous ranges of arena.flat, backward order
         cur, lo = [], 0
-        for p in arena.order:
+        order = arena.order
+        for i, p in enumerate(order):
             cur.append(p)
             hi = arena.offset[id(p)] + p.numel()
-            if hi - lo >= cap:
-                self.buckets.append((lo, (hi + ALIGN - 1) // ALIGN * ALIGN, cur))
-                cur, lo = [], (hi + ALIGN - 1) // ALIGN * ALIGN
+            nxt = order[i + 1] if i + 1 < len(order) else None
+            # a bucket may only end where the next slice starts on its own ALIGN boundary: never inside a tightly packed
+            # q|k|v block (its members' sizes need not be multiples of ALIGN: a rounded-up edge would cut into the next one)
+            if hi - lo >= cap and nxt is not None and id(nxt) not in arena.packed:
+                edge = arena.offset[id(nxt)]
+                self.buckets.append((lo, edge, cur))
+                cur, lo = [], edge
         if cur:
             self.buckets.append((lo, arena.total, cur))
+        self._check_partition()
         self._bucket_of = {id(p): bi for bi, (_, _, ps) in enumerate(self.buckets) for p in ps}
         self._hooks = []
         self._stream = None
         self.enabled = True        # set False on non-boundary micro-steps of gradient accumulation
         self._exposed_ms, self._steps, self._events = 0.0, 0, []
         self._dead = None
+        self._stage = {}
+        self.launch_log = []       # bucket indices in launch order of the current step (tests, diagnostics)
+        self._native = None
+        if native and self.world > 1:
+            self._native = _NativeComm(self.world, self.rank, self.group, arena.flat.device)
         if self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         arena.on_zero.append(self.reset)
         self.reset()
 
+    def _check_partition(self):
+        """the buckets tile [0, total) and every parameter's slice lies inside ITS bucket"""
+        pos = 0
+        for lo, hi, ps in self.buckets:
+            assert lo == pos and hi > lo and lo % ALIGN == 0, (lo, hi, pos)
+            for p in ps:
+                o = self.arena.offset[id(p)]
+                assert lo <= o and o + p.numel() <= hi, "gradient slice crosses a bucket edge"
+            pos = hi
+        assert pos == self.arena.total
+
     def reset(self):
         self._ready = [set() for _ in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._work = []
+        self.launch_log = []
+        self._next = 0
 
     # -- called by autograd right after p.grad has been accumulated ------------------------------
     def _on_grad(self, p):
@@ -171,40 +222,85 @@ class GradReducer:
         self.arena.adopt(p)
         bi = self._bucket_of[id(p)]
         self._ready[bi].add(id(p))
-        if self.overlap and len(self._ready[bi]) == len(self.buckets[bi][2]):
-            self._launch(bi)
+        if self.overlap:
+            self._launch_in_order()
+
+    def _launch_in_order(self, flush=False):
+        """collectives must be issued in the SAME order on every rank: buckets go out strictly in arena (= backward) order,
+        bucket k only once buckets 0..k-1 have gone.  A bucket that is complete before its predecessor (a parameter without a
+        gradient on this rank, a gradient produced out of order) waits for it -- at the latest until finish()."""
+        while self._next < len(self.buckets) and (flush or len(self._ready[self._next]) == len(self.buckets[self._next][2])):
+            self._launch(self._next)
+            self._next += 1
+
+    def _side(self, buf):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=buf.device)
+        return self._stream
 
     def _launch(self, bi):
         if self._launched[bi]:
             return
         self._launched[bi] = True
+        self.launch_log.append(bi)
         lo, hi, ps = self.buckets[bi]
         for p in ps:                          # gradients that arrived while disabled (accumulation) or not at all
             self.arena.adopt(p)
         buf = self.arena.flat[lo:hi]
+        if self.exchange == "bf16":
+            return self._launch_bf16(bi, buf)
         if buf.is_cuda:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(device=buf.device)
-            self._stream.wait_stream(torch.cuda.current_stream(buf.device))
-            with torch.cuda.stream(self._stream):
-                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            side = self._side(buf)
+            side.wait_stream(torch.cuda.current_stream(buf.device))
+            with torch.cuda.stream(side):
+                if self._native is not None:
+                    self._native.allreduce_mean(buf, side)
+                    w = None
+                else:
+                    w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._work.append((w, buf))
+
+    # -- bf16 on the links, float32 accumulation on arrival ---------------------------------------
+    def _launch_bf16(self, bi, buf):
+        n, W = buf.numel(), self.world
+        shard = ((n + W - 1) // W + ALIGN - 1) // ALIGN * ALIGN
+        st = self._stage.get(bi)
+        if st is None:
+            mk = lambda k: torch.zeros(k, dtype=torch.bfloat16, device=buf.device)
+            st = self._stage[bi] = (mk(W * shard), mk(W * shard), mk(shard))       # send, receive / gathered, my reduced shard
+        send, recv, mine = st
+
+        def run():
+            _cast(buf, send[:n])                                   # float32 slice -> bf16 (the tail of `send` stays zero)
+            dist.all_to_all_single(recv, send, group=self.group)   # recv[j*shard:(j+1)*shard] = rank j's shard `rank`
+            _sum_rows(recv.view(W, shard), mine)                   # float32 accumulation, ONE rounding to bf16
+            dist.all_gather_into_tensor(recv, mine, group=self.group)
+            _cast(recv[:n], buf, scale=1.0 / W)                    # mean, back in the float32 arena
+        if buf.is_cuda:
+            side = self._side(buf)
+            side.wait_stream(torch.cuda.current_stream(buf.device))
+            with torch.cuda.stream(side):
+                run()                        # (RCCL collectives called on `side`: stream-ordered, the host does not wait)
+        else:
+            run()
+        self._work.append((None, None))
 
     def finish(self):
         """after backward: flush buckets whose gradients never all arrived, wait for the collectives and leave the
         MEAN in the arena (p.grad of every parameter that received a gradient on ANY rank is its arena slice)."""
         if self.world == 1:
             return
-        for bi in range(len(self.buckets)):
-            self._launch(bi)
+        self._launch_in_order(flush=True)
         cuda = self.arena.flat.is_cuda
         if cuda:
             main = torch.cuda.current_stream(self.arena.flat.device)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main)
         for w, buf in self._work:
+            if w is None:                     # bf16 exchange / native RCCL: already the mean, ordered on the side stream
+                continue
             if cuda:
                 with torch.cuda.stream(self._stream):
                     w.wait()                  # (RCCL: makes the SIDE stream wait for the collective, not the host)
@@ -216,13 +312,20 @@ class GradReducer:
             main.wait_stream(self._stream)
             e1.record(main)
             self._events.append((e0, e1))
-        if self._dead is None:
+        if self._dead is None or (self.recheck_every and self._steps % self.recheck_every == 0):
             # which parameters received a gradient on NO rank (statically dead ones that were not left out of the
-            # arena): decided once, on the first step -- they keep p.grad = None so that the optimizer skips them
-            # exactly as it does in a single process (DDP's find_unused_parameters, made static)
+            # arena): decided on the first step -- they keep p.grad = None so that the optimizer skips them exactly as
+            # it does in a single process (DDP's find_unused_parameters, made static) -- and re-verified now and then:
+            # the reduced bitmap is the same on every rank, so a change raises everywhere at once
             have = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params], device=self.arena.flat.device)
             dist.all_reduce(have, op=dist.ReduceOp.SUM, group=self.group)
-            self._dead = {id(p) for p, h in zip(self.params, have.tolist()) if h == 0.0}
+            dead = {id(p) for p, h in zip(self.params, have.tolist()) if h == 0.0}
+            if self._dead is not None and not self._dead <= dead:
+                raise RuntimeError("GradReducer: a parameter that received no gradient on any rank in the first step "
+                                   "now receives one on some rank; exclude statically dead parameters with "
+                                   "GradArena.for_model(skip=...) or build the reducer after the graph is final")
+            if self._dead is None:
+                self._dead = dead
         for p in self.params:                 # a parameter without a LOCAL gradient still takes part in the mean
             if p.grad is None and id(p) not in self._dead:
                 p.grad = self.arena.view[id(p)]
@@ -234,7 +337,7 @@ class GradReducer:
         ms = [a.elapsed_time(b) for a, b in self._events]
         self._events = []
         return dict(world=self.world, buckets=len(self.buckets), bucket_mb=[round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi, _ in self.buckets],
-                    arena_mb=round(self.arena.total * 4 / 2 ** 20, 1),
+                    arena_mb=round(self.arena.total * 4 / 2 ** 20, 1), exchange=self.exchange, native_rccl=self._native is not None,
                     exposed_comm_ms_per_step=round(sum(ms) / max(1, len(ms)), 3) if ms else None, steps=self._steps)
 
     def broadcast_parameters(self, src=0):
@@ -243,3 +346,58 @@ class GradReducer:
             return
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.group)
+
+    def close(self):
+        if self._native is not None:
+            self._native.close()
+            self._native = None
+
+
+def _cast(src, dst, scale=None):
+    """dst <- src converted to dst's dtype (x scale): the library's cast kernel on the GPU; torch on CPU tensors (gloo tests)"""
+    if src.is_cuda:
+        from . import _hip as H
+        H.check(H.lib().fcmf_cast(H.ptr(src), H.ptr(dst), src.numel(), H.dt(src), H.dt(dst), H.stream()), "fcmf_cast")
+        if scale is not None:
+            dst.mul_(scale)
+    else:
+        dst.copy_(src if scale is None else src.float() * scale)
+
+
+def _sum_rows(x, out):
+    """out[j] = sum_i x[i, j], accumulated in float32, rounded to out's dtype once"""
+    if x.is_cuda:
+        from . import _hip as H
+        H.check(H.lib().fcmf_sum_axis(H.ptr(x), H.ptr(out), 1, x.shape[0], x.shape[1], H.dt(x), H.stream()), "fcmf_sum_axis")
+    else:
+        out.copy_(x.float().sum(0))
+
+
+class _NativeComm:
+    """RCCL communicator owned by libfcmf_hip.so (C ABI `fcmf_dp_*`); the 128-byte unique id travels over the existing
+    torch.distributed group (any backend), the collectives themselves never touch torch.distributed"""
+
+    def __init__(self, world, rank, group, device):
+        import ctypes
+        from . import _hip as H
+        L = H.lib()
+        uid = (ctypes.c_char * 128)()
+        if rank == 0:
+            H.check(L.fcmf_dp_unique_id(ctypes.cast(uid, ctypes.c_void_p)), "fcmf_dp_unique_id")
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = (ctypes.c_char * 128).from_buffer_copy(box[0])
+        self._h = ctypes.c_void_p()
+        torch.cuda.set_device(device)
+        H.check(L.fcmf_dp_comm_create(ctypes.byref(self._h), ctypes.cast(uid, ctypes.c_void_p), world, rank), "fcmf_dp_comm_create")
+
+    def allreduce_mean(self, buf, stream):
+        from . import _hip as H
+        H.check(H.lib().fcmf_dp_allreduce_bucket(self._h, H.ptr(buf), buf.numel(), H.dt(buf), 1, stream.cuda_stream),
+                "fcmf_dp_allreduce_bucket")
+
+    def close(self):
+        from . import _hip as H
+        if self._h:
+            H.lib().fcmf_dp_comm_destroy(self._h)
+            self._h = None

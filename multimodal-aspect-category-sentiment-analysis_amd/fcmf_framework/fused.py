@@ -335,7 +335,7 @@ class SelfLayerFn(torch.autograd.Function):
         wqkv = _fused_weight([wq, wk, wv], dt)
         dx = torch.empty((M, Hd), dtype=dt, device=x2.device)
         wm = _fused_weight([wq, wk, wv], torch.float32)
-        ops.gemm_dx(dqkv, wm if wm.data_ptr() == wq.data_ptr() else None, wqkv, dx, M, Hd, 3 * Hd, aux=dz1, epi=H.EPI_ADD)   # + residual gradient
+        ops.gemm_dx(dqkv, wm if wm.data_ptr() == wq.data_ptr() else None, wqkv, dx, M, Hd, 3 * Hd, aux=dz1, epi=H.EPI_ADD, owner=wq)   # + residual gradient
         side.launch((dqkv, x2), dqkv, x2, G["wqkv"], 3 * Hd, Hd, M, 3 * Hd, Hd, Hd, 1, 1, acc=True)
         side.join()
         W, b = G["wqkv"], G["bqkv"]

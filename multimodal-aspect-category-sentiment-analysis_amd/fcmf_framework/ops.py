@@ -7,6 +7,7 @@ their gradients are always float32.  bf16 copies of the weights ("shadows") are 
 refreshed when the parameter changes.
 """
 import math
+import weakref
 
 import torch
 
@@ -62,27 +63,44 @@ class _Shadows:
         self.mapD = {}
         self._mt_tables = None
 
-    def get_t(self, w):
+    def get_t(self, w, owner=None):
         """bf16 TRANSPOSE [K, N] of a float32 [N, K] weight: dX = dY W then reads W^T as a K-contiguous operand
         (ds_read_b128 instead of transposed LDS reads: the NT kernels run 10-25 % faster than the NN ones).
-        Rebuilt lazily after every optimizer step (one small kernel per weight)."""
+        Rebuilt lazily after every optimizer step (one small kernel per weight).
+        owner: the Parameter whose storage `w` is (a view of); defaults to `w`.  The entry only holds a WEAK reference to
+        it: `refresh_transposed` re-reads the source by raw address, which is only legal while that tensor is alive."""
         key = (w.data_ptr(), tuple(w.shape))
         ent = self.mapT.get(key)
-        if ent is not None and ent[1] == w._version and not ent[2]:
+        owner = w if owner is None else owner
+        if ent is not None and ent[1] == w._version and not ent[2] and ent[4]() is owner:
             return ent[0]
         sh = ent[0] if ent is not None else torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=w.device)
         src = w.detach()
         if not src.is_contiguous():
             src = src.contiguous()
         H.check(H.lib().fcmf_cast_transpose(H.ptr(src), H.ptr(sh), w.shape[0], w.shape[1], H.stream()), "fcmf_cast_transpose")
-        self.mapT[key] = [sh, w._version, False, w.is_contiguous()]
+        self.mapT[key] = [sh, w._version, False, w.is_contiguous(), weakref.ref(owner), w.data_ptr() - owner.data_ptr()]
         return sh
 
+    def _prune_transposed(self):
+        """drop the transposed copies whose source tensor is gone (a freed model: its storage may have been returned to the
+        driver, or recycled for something else) or has moved (`.to()`, re-fused q|k|v storage)"""
+        dead = []
+        for k, ent in self.mapT.items():
+            o = ent[4]()
+            if o is None or o.data_ptr() + ent[5] != k[0]:
+                dead.append(k)
+        for k in dead:
+            del self.mapT[k]
+        if dead:
+            self._mt_tables = None
+
     def refresh_transposed(self):
-        """rebuild EVERY cached transposed copy in one launch (called by the fused optimizers right after their update:
-        all of them are stale at that point, and rebuilding them lazily costs one small launch per weight)"""
+        """rebuild EVERY cached transposed copy of a LIVE weight in one launch (called by the fused optimizers right after
+        their update: all of them are stale at that point, and rebuilding them lazily costs one small launch per weight)"""
         if not self.mapT:
             return
+        self._prune_transposed()
         items = [(k, ent) for k, ent in self.mapT.items() if ent[3]]      # (sources read in place must be dense [R, C])
         if not items:
             return
@@ -103,6 +121,7 @@ class _Shadows:
                 "fcmf_multi_cast_transpose")
         for _, ent in items:
             ent[2] = False
+            ent[1] = ent[4]()._version       # fresh as of the owner's current version
 
     def padded(self, w):
         """the fresh bf16 copy of a 2-D weight including its zero rows up to a multiple of 32"""
@@ -311,11 +330,11 @@ def _ld(x):
     return x.stride(0) if x.shape[0] > 1 else x.shape[1]
 
 
-def gemm_dx(dy, weight, w_compute, dx, M, K_in, N_out, aux=None, epi=H.EPI_NONE, colsum=None):
+def gemm_dx(dy, weight, w_compute, dx, M, K_in, N_out, aux=None, epi=H.EPI_NONE, colsum=None, owner=None):
     """dx [M,K_in] = dy [M,N_out] @ W [N_out,K_in] (+ epilogue).  bf16 mode multiplies by the transposed bf16 copy of the
     float32 master `weight` (an NT GEMM); f32 mode, or a weight without a master, uses `w_compute` as it lies (NN)."""
     if dy.dtype == torch.bfloat16 and weight is not None and weight.dtype == torch.float32 and weight.dim() == 2:
-        wt = shadows.get_t(weight)                                   # [K_in, N_out]
+        wt = shadows.get_t(weight, owner)                            # [K_in, N_out]; owner: the Parameter behind a temporary view
         gemm(dy, wt, dx, M, K_in, N_out, N_out, N_out, K_in, 0, 0, aux=aux, epi=epi, colsum=colsum)
     else:
         gemm(dy, w_compute, dx, M, K_in, N_out, N_out, K_in, K_in, 0, 1, aux=aux, epi=epi, colsum=colsum)

@@ -152,3 +152,134 @@ def test_grad_arena_layout_for_fcmf_model():
         assert all(p.grad is None for p in arena.order)
     finally:
         arena.deactivate()
+
+
+def _fcmf_layout_worker(rank, world, port, q):
+    """the REAL FCMF module tree with a hidden size whose q|k|v members are NOT multiples of the 64-element alignment
+    (H = 40: biases of 40, weights of 1600 elements): buckets must tile the arena, never cut a packed q|k|v block, launch
+    in backward order as their last gradient arrives, and -- with the bf16 exchange -- leave the same bits on both ranks"""
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import tempfile
+    import synthetic_data as synth
+    from fcmf_framework.dp import ALIGN, GradArena, GradReducer
+    from fcmf_framework.fcmf_multimodal import FCMF
+    from fcmf_framework.fused import QKVStorageMixin
+    from fcmf_framework.roberta import RobertaConfig, RobertaModel
+    cfg = dict(synth.TINY_CFG, hidden_size=40, intermediate_size=72)
+    d = tempfile.mkdtemp()
+    torch.manual_seed(0)
+    RobertaModel(RobertaConfig(**cfg)).save_pretrained(d)
+    model = FCMF(d, num_imgs=2, num_roi=3)
+    arena = GradArena.for_model(model)
+    out = {}
+    try:
+        for exchange in ("fp32", "bf16"):
+            red = GradReducer(arena, bucket_mb=0.02, exchange=exchange, recheck_every=1)
+            cap = int(0.02 * 1024 * 1024 / 4)
+            # -- layout ------------------------------------------------------------------------------
+            pos = 0
+            for lo, hi, ps in red.buckets:
+                assert lo == pos and lo % ALIGN == 0
+                pos = hi
+            assert pos == arena.total and len(red.buckets) >= 4
+            biggest = max(p.numel() for p in arena.order)
+            assert all(hi - lo < cap + 3 * biggest + ALIGN for lo, hi, _ in red.buckets)
+            for m in model.modules():
+                if isinstance(m, QKVStorageMixin):
+                    for trio in ((m.query.weight, m.key.weight, m.value.weight), (m.query.bias, m.key.bias, m.value.bias)):
+                        assert len({red._bucket_of[id(p)] for p in trio}) == 1        # a packed block is never cut
+            # -- one step: gradients arrive in backward order; rank r contributes (r + 1) * pattern -------------
+            arena.zero()
+            gen = torch.Generator().manual_seed(5)
+            pattern = {id(p): torch.randn(p.shape, generator=gen) for p in arena.order}
+            seen = []
+            for p in arena.order:
+                p.grad = pattern[id(p)] * (rank + 1)      # produced outside the arena: adopt() copies it into the slice
+                before = len(red.launch_log)
+                red._on_grad(p)
+                bi = red._bucket_of[id(p)]
+                last_of_bucket = p is red.buckets[bi][2][-1]
+                assert (len(red.launch_log) == before + 1) == last_of_bucket             # a bucket goes out with its LAST gradient
+                seen.append(bi)
+            assert red.launch_log == sorted(set(seen)) == list(range(len(red.buckets)))  # backward order, each once
+            red.finish()
+            worst = 0.0
+            for p in arena.order:
+                want = pattern[id(p)] * 1.5                                            # mean of 1x and 2x
+                assert p.grad.data_ptr() == arena.view[id(p)].data_ptr()
+                worst = max(worst, ((p.grad - want).abs().max() / (want.abs().max() + 1e-12)).item())
+            out[exchange] = worst
+            flat = arena.flat.clone()
+            other = [torch.empty_like(flat) for _ in range(world)]
+            dist.all_gather(other, flat)
+            out[exchange + "_same_bits"] = bool(torch.equal(other[0], other[1]))
+            for h in red._hooks:
+                h.remove()
+            arena.on_zero.remove(red.reset)
+        # -- a parameter that turns live on ONE rank after the dead set was fixed must raise on EVERY rank ---------
+        red = GradReducer(arena, bucket_mb=0.02, recheck_every=1)
+        dead_p = arena.order[3]
+        for step in range(2):
+            arena.zero()
+            for p in arena.order:
+                if p is dead_p and not (step == 1 and rank == 1):
+                    continue
+                p.grad = pattern[id(p)].clone()
+                red._on_grad(p)
+            try:
+                red.finish()
+                raised = False
+            except RuntimeError:
+                raised = True
+            out[f"raised{step}"] = raised
+    finally:
+        arena.deactivate()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_fcmf_bucket_layout_order_and_bf16_exchange_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_fcmf_layout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert out["fp32"] < 1e-6, out                      # exact mean
+        assert out["bf16"] < 6e-3, out                      # one bf16 rounding of each rank's contribution + one of the sum
+        assert out["fp32_same_bits"] and out["bf16_same_bits"], out
+        assert out["raised0"] is False and out["raised1"] is True, out
+
+
+def test_default_bucket_plan_for_fcmf_base_geometry():
+    """bucket plan of the FCMF-base arena (156 M parameters; sizes only, no memory): 32 MB buckets -> 11 buckets of 34-40 MB
+    over the encoder / fusion layers, then the 196 MB word-embedding gradient -- ONE tensor, produced by the last backward
+    kernel -- as the final bucket: the part of the exchange nothing can hide"""
+    sys.path.insert(0, PKG)
+    import synthetic_data as synth
+    from fcmf_framework import dp
+    shapes = synth.fcmf_param_shapes(synth.BASE_CFG)
+    sizes = [(n, int(torch.Size(s).numel())) for n, s in shapes.items() if "bert.cell.pooler" not in n]
+    total = sum(k for _, k in sizes)
+    assert 150e6 < total < 160e6
+    cap = 32 * 1024 * 1024 // 4
+    # backward order = reverse registration order
+    buckets, cur = [], 0
+    for n, k in reversed(sizes):
+        cur += k
+        if cur >= cap:
+            buckets.append((n, cur))
+            cur = 0
+    if cur:
+        buckets.append(("tail", cur))
+    assert 10 <= len(buckets) <= 16, len(buckets)
+    assert all(k < 12e6 for _, k in buckets[:-1])                      # <= 48 MB each
+    assert "word_embeddings" in buckets[-1][0] and buckets[-1][1] >= 49e6
+    assert dp.GradReducer.__init__.__defaults__[0] == 32

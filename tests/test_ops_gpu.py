@@ -709,6 +709,34 @@ def test_transposed_weight_copies_refreshed_in_one_launch(dev):
     ops.shadows.clear()
 
 
+def test_transposed_copies_of_freed_weights_are_dropped(dev):
+    """round-2 advisor finding: `refresh_transposed` re-reads every cached source by RAW address.  A weight that has been
+    freed (another model of the same process) must leave the cache before the pointer tables are built -- its address may
+    be unmapped or belong to a different tensor by then -- and a new weight at a recycled address gets a fresh copy."""
+    import gc
+    ops, H = _ops()
+    from fcmf_framework.optimization import FusedAdamW
+    ops.shadows.clear()
+    keep = torch.nn.Parameter(_rand((128, 64), dev, seed=1))
+    gone = torch.nn.Parameter(_rand((256, 64), dev, seed=2))
+    view_owner = torch.nn.Parameter(_rand((96, 64), dev, seed=3))
+    ops.shadows.get_t(keep); ops.shadows.get_t(gone)
+    ops.shadows.get_t(view_owner.detach()[:64], owner=view_owner)      # a temporary view keyed on its Parameter
+    assert len(ops.shadows.mapT) == 3
+    gone_key = (gone.data_ptr(), tuple(gone.shape))
+    del gone
+    gc.collect()
+    opt = FusedAdamW([keep], lr=1e-2)
+    keep.grad = _rand(keep.shape, dev, seed=4)
+    opt.step()                                                         # -> refresh_transposed()
+    assert gone_key not in ops.shadows.mapT and len(ops.shadows.mapT) == 2
+    assert torch.equal(ops.shadows.mapT[(keep.data_ptr(), tuple(keep.shape))][0], keep.detach().t().contiguous().bfloat16())
+    # a NEW weight that lands on the recycled address is never served the dead weight's copy
+    fresh = torch.nn.Parameter(_rand((256, 64), dev, seed=5))
+    assert torch.equal(ops.shadows.get_t(fresh), fresh.detach().t().contiguous().bfloat16())
+    ops.shadows.clear()
+
+
 def test_bertadam_matches_golden(dev):
     import os
     from conftest import GOLD
@@ -782,6 +810,43 @@ def test_attention_mfma_padded_sequences_skip_is_exact(dev, T, p):
         assert not res[True][2][g, l:].any() and not res[True][3][g, l:].any()
 
 
+@pytest.mark.parametrize("T", [128, 100])
+def test_attention_mfma_fully_masked_sequence_is_uniform(dev, T):
+    """a sequence whose EVERY key carries the hard (finfo.min) mask: torch / the reference absorb the scores into finfo.min
+    and softmax is uniform over all T keys (HF eager attention, modeling_roberta.py:158-183).  The MFMA kernels must not
+    shorten such a row to its first key fragment (round-2 advisor finding): out = mean of V, dv = dout / T per key, dq = dk = 0,
+    in both the MFMA and the VALU kernel, next to a normal and a half-padded sequence in the same launch."""
+    from fcmf_framework import ops
+    heads, d = 2, 64
+    HD = heads * d
+    mk = lambda shape, s: _rand(shape, dev, torch.bfloat16, 0.8, seed=s)
+    q0, k0, v0, w = mk((3, T, HD), 1), mk((3, T, HD), 2), mk((3, T, HD), 3), mk((3, T, HD), 4)
+    m01 = torch.ones(3, T)
+    m01[1] = 0                      # sequence 1: no live key at all
+    m01[2, T // 2:] = 0
+    mask = ((1 - m01) * torch.finfo(torch.float32).min).to(dev)
+    # torch fp32 reference of the same op
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q0, k0, v0))
+    sp = lambda t: t.view(3, T, heads, d).transpose(1, 2)
+    sc = sp(qr) @ sp(kr).transpose(-1, -2) / math.sqrt(d) + mask[:, None, None, :]
+    ref = (torch.softmax(sc, -1) @ sp(vr)).transpose(1, 2).reshape(3, T, HD)
+    (ref * w.float()).sum().backward()
+    for use in (True, False):
+        ops.USE_MFMA_ATTENTION = use
+        try:
+            q, k, v = (t.clone().requires_grad_(True) for t in (q0, k0, v0))
+            out = ops.attention(q, k, v, mask=mask, heads=heads, p=0.0, training=False)
+            (out.float() * w.float()).sum().backward()
+        finally:
+            ops.USE_MFMA_ATTENTION = True
+        assert rel_err(out, ref) < 2e-2, use
+        assert rel_err(v.grad, vr.grad) < 3e-2, use
+        assert rel_err(q.grad[[0, 2]], qr.grad[[0, 2]]) < 3e-2 and rel_err(k.grad[[0, 2]], kr.grad[[0, 2]]) < 3e-2, use
+        # the fully masked sequence: uniform probabilities -> no dependence on q / k
+        assert q.grad[1].float().abs().max().item() < 1e-2 * qr.grad[0].abs().max().item(), use
+        assert k.grad[1].float().abs().max().item() < 1e-2 * kr.grad[0].abs().max().item(), use
+
+
 @pytest.mark.parametrize("Tq,Tk", [(128, 128), (77, 128), (128, 50), (33, 17), (256, 256), (200, 256), (256, 150), (130, 129)])
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_attention_mfma_matches_reference_and_valu_kernel(dev, Tq, Tk, p):
@@ -816,3 +881,33 @@ def test_attention_mfma_matches_reference_and_valu_kernel(dev, Tq, Tk, p):
         (ref * w.double().cpu()).sum().backward()
         for a, b, name in zip(res[True], (ref, qr.grad, kr.grad, vr.grad), ("out", "dq", "dk", "dv")):
             assert rel_err(a, b) < 3e-2, name
+
+
+def test_dp_allreduce_bucket_c_abi_single_rank(dev):
+    """the RCCL entry points of the C ABI (include/fcmf_hip.h `fcmf_dp_*`; reference: init_process_group("nccl") + DDP,
+    run_multimodal_fcmf.py:169,237-240) on the one GPU of this box: unique id, a 1-rank communicator, the in-place mean of a
+    float32 and of a bf16 bucket on a side stream (= identity at world size 1), argument errors, destroy.  The multi-rank
+    exchange itself is covered by the gloo tests (tests/test_dp_gloo.py); RCCL across GPUs needs the 8-GPU node."""
+    import ctypes
+    ops, H = _ops()
+    L = H.lib()
+    uid = (ctypes.c_char * 128)()
+    H.check(L.fcmf_dp_unique_id(ctypes.cast(uid, ctypes.c_void_p)), "fcmf_dp_unique_id")
+    assert any(bytes(uid))
+    h = ctypes.c_void_p()
+    torch.cuda.set_device(dev)
+    H.check(L.fcmf_dp_comm_create(ctypes.byref(h), ctypes.cast(uid, ctypes.c_void_p), 1, 0), "fcmf_dp_comm_create")
+    assert h.value
+    side = torch.cuda.Stream(device=dev)
+    for dtype in (torch.float32, torch.bfloat16):
+        buf = _rand((1 << 20,), dev, dtype, seed=3)
+        want = buf.clone()
+        side.wait_stream(torch.cuda.current_stream(dev))
+        H.check(L.fcmf_dp_allreduce_bucket(h, H.ptr(buf), buf.numel(), H.dt(buf), 1, side.cuda_stream), "fcmf_dp_allreduce_bucket")
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want)
+    assert L.fcmf_dp_allreduce_bucket(h, 0, 4, H.F32, 1, 0) == -1                     # null buffer
+    assert L.fcmf_dp_allreduce_bucket(h, H.ptr(buf), 4, H.F64, 1, 0) == -3            # unsupported dtype
+    assert L.fcmf_dp_comm_create(ctypes.byref(ctypes.c_void_p()), ctypes.cast(uid, ctypes.c_void_p), 2, 5) == -1
+    H.check(L.fcmf_dp_comm_destroy(h), "fcmf_dp_comm_destroy")

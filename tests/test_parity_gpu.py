@@ -5,8 +5,11 @@ C ABI) against (1) the committed golden fixtures produced by the REFERENCE impor
 Tolerances
   fp32 path : logits / loss within 1e-3 absolute -- the bound BASELINE.json's north_star states
               ("match the CPU reference within 1e-3 fp32"); measured errors are ~1e-5.
-  bf16 path : logits within 6e-2 absolute (bf16 activations: 8 significant bits through 12+ layers;
-              SURVEY.md section 5.9 measured 4.3e-3 for bf16 autocast on the reference itself).
+  bf16 path : SCALE-AWARE bounds (round-2 verdict: a 6e-2 absolute bound is vacuous on logits of |max| 0.08 - 0.43):
+              logits within 2e-2 x |ref|max AND within 0.25 x the reference's cross-sample spread where the fixture has
+              one that bf16 can resolve (FCMF-base: 0.05); gradients per parameter within 3e-2 of the reference norm,
+              cosine >= 0.999 on the fixture's sampled elements and against the full fp32 gradient.
+              Measured on MI355X: see the numbers next to each bound.
 """
 import os
 
@@ -20,6 +23,54 @@ from oracle import fcmf_oracle as O
 import synthetic_data as synth
 
 pytestmark = pytest.mark.gpu
+
+
+def _bf16_logit_tol(ref, use_spread=True):
+    """bf16 logit bound from the REFERENCE logits [B, A, C]: 2 % of their magnitude, and (where bf16 can resolve it) a
+    quarter of the spread across the samples of the batch -- a model that ignored its inputs could not meet that"""
+    ref = torch.as_tensor(ref).float()
+    tol = 2e-2 * ref.abs().max().item()
+    if use_spread and ref.shape[0] > 1:
+        spread = ref.std(dim=0).max().item()
+        if spread > 8e-3 * ref.abs().max().item():      # (tiny fixture: spread 2.5e-4 on |0.08| is below bf16 resolution)
+            tol = min(tol, 0.25 * spread)
+    return tol
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-300)).item()
+
+
+ZERO_GRAD = (".key.bias", "box_head.linears.1.bias")      # analytically zero (softmax shift invariance): rounding noise only
+
+
+def _check_grads_against_fixture(named, z, rel_norm_tol, cos_tol, floor=1e-5):
+    """per-parameter gradient norms against the reference fixture's `grad_norms`, and the cosine over ALL the fixture's
+    sampled gradient elements (`g_*`, 16 parameters from every part of the model)"""
+    worst = ("", 0.0)
+    for n, ref_norm in zip([str(x) for x in z["grad_names"]], z["grad_norms"]):
+        if n.endswith(ZERO_GRAD) or ref_norm < floor:
+            continue
+        g = named[n].grad
+        assert g is not None and torch.isfinite(g).all(), n
+        r = abs(g.float().norm().item() - ref_norm) / ref_norm
+        if r > worst[1]:
+            worst = (n, r)
+    got, ref = [], []
+    for key in z.files:
+        if key.startswith("g_"):
+            n = key[2:]
+            g = named[n].grad.float().flatten().cpu()
+            if ("gidx_" + n) in z.files:
+                g = g[torch.from_numpy(z["gidx_" + n])]
+            r = torch.from_numpy(z[key]).float()
+            # every parameter weighs the same in the cosine (their gradient scales differ by 1e4)
+            got.append(g / (r.norm() + 1e-30)); ref.append(r / (r.norm() + 1e-30))
+    c = _cos(torch.cat(got), torch.cat(ref))
+    assert worst[1] < rel_norm_tol, ("gradient norm vs reference", worst)
+    assert c > cos_tol, ("cosine over the sampled reference gradient elements", c)
+    return worst, c
 
 
 def _set(dtype):
@@ -133,7 +184,8 @@ def test_tiny_bf16_close_to_reference(tiny, dev):
     _set(torch.bfloat16)
     try:
         la = _run_aspects(model, batch_to(batch, dev))
-        assert max_err(la, torch.from_numpy(z["logits"])) < 6e-2
+        # |ref|max 0.081 -> bound 1.6e-3; measured 4.2e-4 (GPUTEST_r02 smoke line)
+        assert max_err(la, torch.from_numpy(z["logits"])) < _bf16_logit_tol(z["logits"])
     finally:
         _set(torch.float32)
 
@@ -203,7 +255,13 @@ def test_base_bf16_close_and_aspect_batching_is_exact(base, dev):
         with torch.no_grad():
             la = _run_aspects(model, b)
             lp = _run_per_aspect(model, b)
-        assert max_err(la, torch.from_numpy(z["logits"])) < 6e-2
+        # |ref|max 0.43, cross-sample spread 0.05 -> bound min(8.6e-3, 1.27e-2) = 8.6e-3
+        assert max_err(la, torch.from_numpy(z["logits"])) < _bf16_logit_tol(z["logits"]), max_err(la, torch.from_numpy(z["logits"]))
+        # ... and the input-DEPENDENT part (sample 0 minus sample 1) must be reproduced, not just the common offset
+        dref = torch.from_numpy(z["logits"][0] - z["logits"][1])
+        dgot = (la[0] - la[1]).float().cpu()
+        assert (dgot - dref).abs().max().item() < 0.1 * dref.abs().max().item(), ((dgot - dref).abs().max().item(), dref.abs().max().item())
+        assert _cos(dgot, dref) > 0.995
         # batching the aspects must not change any row's arithmetic
         assert max_err(la, lp) < 1e-6
     finally:
@@ -282,7 +340,7 @@ def test_config1_batch64_rows_match_reference(base, dev):
     z, model, _ = base
     b = batch_to(_batch64_with_fixture_rows(), dev)
     ref = torch.from_numpy(z["logits"])
-    for dtype, tol in ((torch.bfloat16, 6e-2), (torch.float32, 1e-3)):
+    for dtype, tol in ((torch.bfloat16, _bf16_logit_tol(ref)), (torch.float32, 1e-3)):
         _set(dtype)
         try:
             with torch.no_grad():
@@ -290,7 +348,9 @@ def test_config1_batch64_rows_match_reference(base, dev):
             assert la.shape == (64, 6, 4) and torch.isfinite(la).all()
             assert max_err(la[:2], ref) < tol, (dtype, max_err(la[:2], ref))
             loss2 = model.loss_aspects(la[:2].float(), b["labels"][:2])
-            assert abs(loss2.item() - float(z["loss"])) < tol, (dtype, loss2.item(), float(z["loss"]))
+            # (the loss sums 6 per-aspect mean CEs: six times the logit bound in bf16)
+            ltol = tol if dtype == torch.float32 else 6 * tol
+            assert abs(loss2.item() - float(z["loss"])) < ltol, (dtype, loss2.item(), float(z["loss"]))
         finally:
             _set(torch.float32)
 
@@ -332,6 +392,159 @@ def test_config1_batch64_gradients_equal_sum_of_shards_bf16(dev):
         assert worst[1] < 0.15, worst
     finally:
         _set(torch.float32)
+        model.zero_grad(set_to_none=True)
+
+
+def _named_grads(model):
+    return {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def test_base_bf16_gradients_match_reference(base, dev):
+    """FCMF-base, the bf16 (MFMA) training graph on the fixture batch (B=2, dropout off): the gradient of EVERY live
+    parameter against the REFERENCE's fixture -- per-parameter norm within 3e-2, cosine >= 0.999 over the fixture's sampled
+    elements -- and against the full fp32-path gradient (itself pinned to the fixture at 1e-3 by
+    test_base_fp32_matches_reference_within_north_star_tolerance): global cosine >= 0.999."""
+    z, model, batch = base
+    b = batch_to(batch, dev)
+    named = dict(model.named_parameters())
+    try:
+        _set(torch.bfloat16)
+        model.zero_grad(set_to_none=True)
+        la = _run_aspects(model, b)
+        loss = model.loss_aspects(la, b["labels"])
+        assert abs(loss.item() - float(z["loss"])) < 6 * _bf16_logit_tol(z["logits"])
+        loss.backward()
+        worst, c = _check_grads_against_fixture(named, z, rel_norm_tol=3e-2, cos_tol=0.999)
+        g16 = _named_grads(model)
+        _set(torch.float32)
+        model.zero_grad(set_to_none=True)
+        model.loss_aspects(_run_aspects(model, b), b["labels"]).backward()
+        g32 = _named_grads(model)
+        keys = [n for n in g32 if not n.endswith(ZERO_GRAD)]
+        # global cosine with every parameter normalised by its own fp32 norm (scales differ by 1e4 across the model)
+        a = torch.cat([(g16[n] / (g32[n].norm() + 1e-30)).flatten() for n in keys])
+        r = torch.cat([(g32[n] / (g32[n].norm() + 1e-30)).flatten() for n in keys])
+        assert _cos(a, r) > 0.999, _cos(a, r)
+        print(f"bf16 grads vs reference: worst norm err {worst}, sampled cosine {c:.6f}, full cosine vs fp32 {_cos(a, r):.6f}")
+    finally:
+        _set(torch.float32)
+        model.zero_grad(set_to_none=True)
+
+
+def test_config1_batch64_bf16_gradient_of_fixture_rows_matches_reference(base, dev):
+    """BASELINE configs[1] at its own batch, the bf16 training graph (M = 49152-row GEMMs, 192-row tiles, split-K weight
+    gradients over K = 49152 tokens): the loss is taken over reviews 0-1 only -- the fixture batch -- so the gradient of the
+    whole B=64 graph must equal the REFERENCE's fixture gradient (the other 62 reviews contribute exact zeros)."""
+    z, model, _ = base
+    b = batch_to(_batch64_with_fixture_rows(), dev)
+    named = dict(model.named_parameters())
+    try:
+        _set(torch.bfloat16)
+        model.zero_grad(set_to_none=True)
+        la = _run_aspects(model, b)
+        model.loss_aspects(la[:2], b["labels"][:2]).backward()
+        worst, c = _check_grads_against_fixture(named, z, rel_norm_tol=3e-2, cos_tol=0.999)
+        print(f"B=64 bf16 grads of fixture rows vs reference: worst norm err {worst}, sampled cosine {c:.6f}")
+    finally:
+        _set(torch.float32)
+        model.zero_grad(set_to_none=True)
+
+
+def _tiny_train_loss(model, b, seed):
+    from fcmf_framework import ops
+    ops.manual_seed(seed)
+    return model.loss_aspects(_run_aspects(model, b), b["labels"])
+
+
+def test_dropout_on_graph_backward_matches_finite_differences(tiny, dev):
+    """the graph bench.py times has dropout ON: every mask is a counter-based hash regenerated inside the backward kernels
+    (DESIGN section 3.4).  With a fixed seed the dropout-on step is a deterministic, smooth function of the parameters, so
+    the backward is checked at MODEL level against central finite differences of the forward along random directions
+    (fp32 mode: FD noise ~1e-3): a backward kernel that regenerated a different mask than its forward fails this."""
+    z, model, P, batch = tiny
+    model.load_state_dict(P)
+    _set(torch.float32)
+    b = batch_to(batch, dev)
+    model.train()
+    try:
+        params = [p for n, p in model.named_parameters() if "bert.cell.pooler" not in n]
+        model.zero_grad(set_to_none=True)
+        l0 = _tiny_train_loss(model, b, 123)
+        l0.backward()
+        g = [p.grad.detach().clone() for p in params]
+        model.zero_grad(set_to_none=True)
+        l1 = _tiny_train_loss(model, b, 123)
+        l1.backward()
+        assert l0.item() == l1.item()                                     # same seed -> same masks -> same bits
+        assert all(torch.equal(a, p.grad) for a, p in zip(g, params))
+        l2 = _tiny_train_loss(model, b, 124)
+        assert l2.item() != l0.item()                                     # another seed -> other masks
+        for trial in range(3):
+            gen = torch.Generator().manual_seed(trial)
+            vs = [(torch.randn(p.shape, generator=gen).to(dev) * p.detach().abs().mean().clamp_min(1e-3)) for p in params]
+            dd = sum((a.double() * v.double()).sum().item() for a, v in zip(g, vs))
+            eps = 2e-3
+            with torch.no_grad():
+                for p, v in zip(params, vs):
+                    p.add_(v, alpha=eps)
+                lp = _tiny_train_loss(model, b, 123).double().item()
+                for p, v in zip(params, vs):
+                    p.add_(v, alpha=-2 * eps)
+                lm = _tiny_train_loss(model, b, 123).double().item()
+                for p, v in zip(params, vs):
+                    p.add_(v, alpha=eps)
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - dd) < 3e-2 * max(abs(dd), abs(fd)) + 2e-4, (trial, fd, dd)
+    finally:
+        model.eval()
+        model.load_state_dict(P)
+        model.zero_grad(set_to_none=True)
+
+
+def test_dropout_on_bf16_gradients_agree_with_fp32_same_masks_and_are_unbiased(tiny, dev):
+    """(1) the masks depend on (seed, element index) only, not on the activation dtype: the bf16 dropout-on gradient
+    equals the fp32 dropout-on gradient of the same seed within bf16 rounding (cosine >= 0.99 per the whole model);
+    (2) statistically: over 24 seeds the mean dropout-on loss sits within a few standard errors (+ a small curvature term)
+    of the p = 0 loss and the mean gradient points along the p = 0 gradient -- a missing 1/(1-p) rescale (10 % per site,
+    compounding over the layers) or a mask applied in the forward only would move both far outside."""
+    z, model, P, batch = tiny
+    model.load_state_dict(P)
+    b = batch_to(batch, dev)
+    names = [n for n, p in model.named_parameters() if "bert.cell.pooler" not in n and not n.endswith(ZERO_GRAD)]
+    named = dict(model.named_parameters())
+
+    def flat_grad(dtype, seed, train=True):
+        _set(dtype)
+        model.train(train)
+        model.zero_grad(set_to_none=True)
+        loss = _tiny_train_loss(model, b, seed)
+        loss.backward()
+        g32 = torch.cat([named[n].grad.float().flatten() for n in names])
+        return loss.item(), g32
+
+    try:
+        l32, g32 = flat_grad(torch.float32, 7)
+        l16, g16 = flat_grad(torch.bfloat16, 7)
+        assert abs(l16 - l32) < 2e-2 * abs(l32), (l16, l32)
+        assert _cos(g16, g32) > 0.99, _cos(g16, g32)
+        l0, g0 = flat_grad(torch.bfloat16, 0, train=False)                # p = 0
+        ls, gs = [], torch.zeros_like(g0)
+        NS = 24
+        for sd in range(100, 100 + NS):
+            l, g = flat_grad(torch.bfloat16, sd)
+            ls.append(l)
+            gs += g / NS
+        mean = sum(ls) / NS
+        sem = (sum((x - mean) ** 2 for x in ls) / (NS - 1)) ** 0.5 / NS ** 0.5
+        assert abs(mean - l0) < 4 * sem + 2e-2 * abs(l0), (mean, l0, sem)
+        assert _cos(gs, g0) > 0.9, _cos(gs, g0)
+        assert 0.7 < gs.norm().item() / g0.norm().item() < 1.4, (gs.norm().item(), g0.norm().item())
+        print(f"dropout-on: bf16-vs-fp32 same-seed cosine {_cos(g16, g32):.5f}; mean loss {mean:.5f} vs p=0 {l0:.5f} (sem {sem:.5f}); "
+              f"mean-gradient cosine {_cos(gs, g0):.4f}, norm ratio {gs.norm().item() / g0.norm().item():.3f}")
+    finally:
+        _set(torch.float32)
+        model.eval()
+        model.load_state_dict(P)
         model.zero_grad(set_to_none=True)
 
 
@@ -381,7 +594,7 @@ def test_fcmf_large_geometry_bf16_and_fp32(dev):
         _set(torch.bfloat16)
         model.zero_grad(set_to_none=True)
         l16 = _run_aspects(model, b)
-        assert max_err(l16, l32) < 6e-2, max_err(l16, l32)
+        assert max_err(l16, l32) < _bf16_logit_tol(l32.detach().cpu(), use_spread=False), (max_err(l16, l32), l32.abs().max().item())
         model.loss_aspects(l16, b["labels"]).backward()
         for n, p in model.named_parameters():
             if "bert.cell.pooler" in n:
@@ -515,7 +728,8 @@ def test_iaog_bf16_no_grad_and_accumulation(dev):
             lg1 = _iaog_forward(model, batch, dec)
             lg2 = _iaog_forward(model, batch, dec)
         assert torch.equal(lg1, lg2)
-        assert max_err(lg1[:, :, ::8].float(), torch.from_numpy(z[t + "logits"])) < 6e-2
+        ref_lg = torch.from_numpy(z[t + "logits"])
+        assert max_err(lg1[:, :, ::8].float(), ref_lg) < 2e-2 * ref_lg.abs().max().item(), (max_err(lg1[:, :, ::8].float(), ref_lg), ref_lg.abs().max().item())
         g16 = grads(torch.bfloat16)
         g32 = grads(torch.float32)
         num = den = 0.0
@@ -529,3 +743,64 @@ def test_iaog_bf16_no_grad_and_accumulation(dev):
         assert (num / den) ** 0.5 < 3e-2
     finally:
         _set(torch.float32)
+
+
+def test_iaog_config3_full_size_bf16(dev):
+    """BASELINE configs[3] at its OWN geometry per GPU (PhoBERT-base encoder, vocabulary 64001, batch 64, seq 128, decoder
+    length 12, 12 decoder blocks, 4 ROIs): no reference fixture exists at this size (a 262 M-parameter CPU step), so
+    size-independent properties: finite, bit-deterministic, the fused projection + loss node == the unfused
+    logits -> CrossEntropy path (same kernels for the projection: equal within bf16 rounding of the loss), loss near ln V
+    for random-init weights, every live parameter receives a finite gradient, the tied vocabulary matrix receives the SUM
+    of its two uses, and the wide-vocabulary kernels see the ragged 64001 -> 64032 padding."""
+    import math
+    from fcmf_framework import ops
+    from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq
+    from helpers import make_hf_dir
+    cfg = synth.BASE_CFG
+    V, NI, NR, B, S, Ld = cfg["vocab_size"], 7, 4, 64, 128, 12
+    torch.manual_seed(0)
+    model = FCMFSeq2Seq(V, 20, make_hf_dir(cfg), NI, NR, 1.0)
+    model.decoder.embedding = torch.nn.Embedding(V, model.decoder.num_hiddens)       # run_pretraining_fcmf.py:189
+    model = model.to(dev).eval()
+    b = batch_to(synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, num_aspects=1, seed=3, coord_dtype=torch.float32), dev)
+    dec = torch.randint(3, V, (B, Ld), generator=torch.Generator().manual_seed(1)).to(dev)
+    lab = torch.roll(dec, -1, dims=1)
+    lab[:, -1] = -100                                                                 # iaog_dataset.py:93-96
+    lab[5, 3:] = -100                                                                 # a short target: ignored tail
+    args = (b["visual_embeds_att"], b["roi_embeds_att"], b["roi_coors"], b["token_type_ids"][:, 0], b["attention_mask"][:, 0],
+            b["added_attention_mask"][:, 0])
+    _set(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            lg = model(b["input_ids"][:, 0], dec, *args, None, is_train=True)
+            assert lg.shape == (B, Ld, V) and torch.isfinite(lg).all()
+            unfused = ops.cross_entropy(lg, lab, ignore_index=-100).item()
+            del lg
+            f1 = model.forward_loss(b["input_ids"][:, 0], dec, lab, *args).item()
+            f2 = model.forward_loss(b["input_ids"][:, 0], dec, lab, *args).item()
+        assert f1 == f2                                                               # deterministic
+        assert abs(f1 - unfused) < 2e-3 * abs(unfused), (f1, unfused)
+        assert abs(f1 - math.log(V)) < 0.15 * math.log(V), f1                          # random init: ~uniform predictions
+        model.zero_grad(set_to_none=True)
+        loss = model.forward_loss(b["input_ids"][:, 0], dec, lab, *args)
+        loss.backward()
+        tied = model.encoder.bert.cell.embeddings.word_embeddings.weight
+        assert model.decoder.dense.weight is tied
+        for n, p in model.named_parameters():
+            if "bert.cell.pooler" in n:
+                assert p.grad is None
+            else:
+                assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        # the tied matrix: rows of target tokens get a projection gradient even where the encoder never embedded them
+        used_by_encoder = torch.zeros(V, dtype=torch.bool, device=dev)
+        used_by_encoder[b["input_ids"][:, 0].reshape(-1)] = True
+        tgt = lab[lab >= 0].unique()
+        only_dec = tgt[~used_by_encoder[tgt]]
+        assert only_dec.numel() > 0 and (tied.grad[only_dec].abs().sum(1) > 0).all()
+        # the decoder's own (untied) embedding table: exactly the rows of the decoder inputs are touched
+        eg = model.decoder.embedding.weight.grad
+        touched = (eg.abs().sum(1) > 0).nonzero().flatten()
+        assert set(touched.tolist()) <= set(dec.unique().tolist()) and touched.numel() > 0.9 * dec.unique().numel()
+    finally:
+        _set(torch.float32)
+        model.zero_grad(set_to_none=True)
