@@ -220,7 +220,7 @@ def run_fcmf(args, rank, world, dev, large=False):
     host = synth.synth_batch(B, CFG, S=S, num_imgs=NI, num_roi=NR, num_aspects=A, seed=42 + rank)
     batch = {k: v.to(dev) for k, v in host.items()}
 
-    def step():
+    def step(batch=batch):
         if arena is not None:
             arena.zero()
         else:
@@ -240,7 +240,10 @@ def run_fcmf(args, rank, world, dev, large=False):
     comm = red.stats() if red is not None else None
     if rank != 0:
         return None
-    # host -> HBM copy of one batch from pinned memory (never part of `value`: inputs are resident before the timed region)
+    # host -> HBM: (1) the bare copy of one batch from pinned memory; (2) the step loop fed through the drivers' DevicePrefetcher --
+    # every step consumes a FRESH host batch (pinned producer buffers, copy stream, one batch ahead): `value_with_h2d` is that
+    # loop's rate.  Never part of `value` (inputs are resident before ITS timed region).
+    from device_prefetch import DevicePrefetcher
     pinned = {k: v.pin_memory() for k, v in host.items()}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -249,6 +252,15 @@ def run_fcmf(args, rank, world, dev, large=False):
     torch.cuda.synchronize()
     h2d_ms = (time.perf_counter() - t0) / 3 * 1e3
     del tmp
+    n_pf = max(3, min(args.steps, 8))
+    pf = iter(DevicePrefetcher((pinned for _ in range(n_pf + 1)), dev))
+    step(next(pf))                                   # (pipeline fill: the first copy is exposed by construction)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in pf:
+        step(b)
+    torch.cuda.synchronize()
+    ms_step_pf = (time.perf_counter() - t0) / n_pf * 1e3
     ms_step = dt / args.steps * 1e3
     out = {
         "metric": "train samples/sec (fwd+bwd+step) FCMF-large seq256x100ROI (bf16; the fp8 path of BASELINE configs[4] is not built)"
@@ -267,7 +279,9 @@ def run_fcmf(args, rank, world, dev, large=False):
                    "dense_flops_per_sample_fwd_bwd": algorithmic_flops_per_sample(CFG, S, NI, 49, NR, A)},
         "loss": round(float(loss.item()), 4),
         "h2d_ms_per_batch": round(h2d_ms, 2),
-        "value_with_h2d": round(world * B / ((ms_step + h2d_ms) * 1e-3), 2),
+        "value_with_h2d": round(world * B / (ms_step_pf * 1e-3), 2),
+        "ms_per_step_with_h2d": round(ms_step_pf, 2),
+        "h2d": f"{n_pf} steps, each on a fresh pinned host batch through device_prefetch.DevicePrefetcher (copy stream, one batch ahead)",
         "roofline": gemm_roofline(trace),
     }
     if comm is not None:

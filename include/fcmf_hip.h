@@ -45,12 +45,37 @@ int fcmf_abi_version(void);
 const char* fcmf_build_info(void);
 
 /* ---------------------------------------------------------------------------------------
+ * GEMM context: everything fcmf_gemm uses beyond its arguments.  The library keeps NO mutable process-global state; a
+ * context is owned by the caller and used by one host thread / one stream at a time (the Python layer keeps one per
+ * (device, stream)).  NULL is a valid context: defaults, no split-K workspace.
+ *   set_workspace: caller-owned DEVICE scratch for the k-split partial tiles of weight-gradient GEMMs (accumulate != 0):
+ *                  with at least ksplit*M*N*4 bytes the partials are written with plain stores and summed by a reduce
+ *                  pass (5x cheaper than 65 536 float atomics per CU); without it, or when it is too small, float
+ *                  atomics.  The buffer must stay valid until the stream has drained.  ptr = NULL unregisters.
+ *   tune         : benchmark / test knobs; a negative value keeps the current setting.
+ *                  force_tile 0 = built-in heuristic, 128 = 128x128 kernel, 256 / 192 = persistent 256x256 / 192x256 kernel
+ *                  wherever its preconditions hold; kb 32 / 64 = depth of the k-tiles of the K-contiguous persistent kernels
+ *                  (both depths issue the same MFMAs in the same order: bit-identical results); num_cus = workgroups of
+ *                  the persistent kernels (8..256; leaves CUs to kernels that run beside them, e.g. RCCL);
+ *                  nt_min_bytes = bf16 outputs of at least this size leave with nontemporal stores (default 0 = all).
+ *   last_kernel  : name of the kernel the context's last fcmf_gemm dispatched, e.g.
+ *                  "gemm_bf16_tile256_kernel<0,1,bf16,GELU>" (benchmarks attribute launch time by it; host string owned
+ *                  by the context). */
+typedef struct fcmf_gemm_ctx fcmf_gemm_ctx;
+int fcmf_gemm_ctx_create(fcmf_gemm_ctx** ctx);
+int fcmf_gemm_ctx_destroy(fcmf_gemm_ctx* ctx);
+int fcmf_gemm_ctx_set_workspace(fcmf_gemm_ctx* ctx, void* ptr, int64_t bytes);
+int fcmf_gemm_ctx_tune(fcmf_gemm_ctx* ctx, int force_tile, int kb, int num_cus, int64_t nt_min_bytes);
+const char* fcmf_gemm_ctx_last_kernel(const fcmf_gemm_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------
  * GEMM:  C[M,N] (+)= epilogue( op(A)[M,K] * op(B)[K,N] + bias[N] )
+ *   ctx: GEMM context (above) or NULL.
  *   trans_a = 0: A stored [M,K] (row stride lda)      trans_a = 1: A stored [K,M]
  *   trans_b = 0: B stored [N,K] (nn.Linear weight)    trans_b = 1: B stored [K,N]
  *   in_dtype: dtype of A and B; out_dtype: dtype of C and aux; bias is float32 or NULL.
- *   accumulate != 0 (out_dtype must be F32): C += result (split-K partials are added
- *   with float atomics, so C must be initialised).
+ *   accumulate != 0 (out_dtype must be F32): C += result (k-split partials go through the context's workspace, or are
+ *   added with float atomics when there is none -- C must be initialised either way).
  *   colsum (float32 [N], may be NULL; not with accumulate): colsum[n] += sum_m C[m,n] -- the bias
  *   gradient of the layer that produced the operand, fused into the epilogue.
  * Replaces nn.Linear forward/backward everywhere on the path: mm_modeling.py:182-184,
@@ -58,27 +83,10 @@ const char* fcmf_build_info(void);
  * fcmf_multimodal.py:18 and their autograd (dX = dY*W, dW = dY^T*X).
  * bf16 inputs whose contiguous dimensions are multiples of 8 elements with 16-byte aligned
  * bases run on the MFMA bf16 kernel; everything else runs on the generic f32-MFMA kernel. */
-int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
+int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
               int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
               int trans_a, int trans_b, int in_dtype, int out_dtype,
               int epilogue, int accumulate, void* stream);
-
-/* tuning hook for benchmarks/tests: 0 = built-in heuristic; 128 = 128x128 kernel, 256 / 192 = persistent
- * 256x256 / 192x256 kernel wherever its preconditions hold */
-void fcmf_gemm_force_tile(int tile);
-/* 32: keep the 32-deep k-tile kernels everywhere; anything else: 64-deep k-tiles where they apply (the default).  The two
- * depths issue the same MFMAs in the same order: results are bit-identical (tests rely on that). */
-void fcmf_gemm_force_kb(int kb);
-
-/* Optional caller-owned scratch for split-K weight-gradient GEMMs issued on `stream`: with at least
- * ksplit*M*N*4 bytes registered the k-split partial tiles are written with plain stores and summed by a reduce
- * pass (5x cheaper than 65 536 float atomics per CU); without it, or when it is too small, the GEMM uses float
- * atomics.  ptr = NULL unregisters.  The buffer must stay valid until the stream has drained. */
-int fcmf_gemm_set_workspace(void* ptr, int64_t bytes, void* stream);
-
-/* name of the kernel the calling thread's last fcmf_gemm dispatched, e.g. "gemm_bf16_tile256_kernel<0,1,bf16,GELU>"
- * (benchmarks attribute launch time by it; the string lives in thread-local storage of the library) */
-const char* fcmf_gemm_last_kernel(void);
 
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X dtype = dtype, out float32. */
 int fcmf_colsum(const void* X, float* out, int M, int N, int64_t ldx, int dtype,

@@ -441,6 +441,7 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
   const float inv_keep = P.p > 0.f ? 1.0f / (1.0f - P.p) : 1.0f;
   const uint64_t drop_base = ((uint64_t)g * P.heads + h) * P.Tq * P.Tk;      // dropout counter of (query 0, key 0)
   const float* mrow = P.mask ? P.mask + kbase : nullptr;
+  float score_scale = P.scale;            // (0 for a sequence whose every key is hard-masked: see below)
   // operands that stay in registers, per query tile: the wave's 32 query rows of Q and dO (phase 1) and the transposed
   // 16-column slices dO^T / Q^T [d = 16w ..][q] that dV / dK of every key chunk multiply (phase 2)
   bf16x8 qa[NQT][2][2], da[NQT][2][2], oT[NQT][4], qT[NQT][4];
@@ -483,6 +484,20 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
       if (b) last = 64 * i + 63 - __builtin_clzll(b);
     }
     nvalid = last >= 0 ? last + 1 : P.Tk;    // no live key at all: nothing may be skipped (softmax over finfo.min scores is uniform over ALL keys)
+    // ... and the forward's logsumexp of such a sequence is finfo.min itself (log Tk is absorbed), from which exp(s + mask - lse)
+    // would recompute probabilities of 1 instead of 1 / Tk.  Wave-uniform substitution, no per-element work: drop the mask and
+    // the scores and take lse = log Tk.
+    if (last < 0) {
+      mrow = nullptr;
+      score_scale = 0.f;
+      const float ltk = __logf((float)P.Tk);
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lse4[qt][f][r] = ltk;
+    }
   }
   const int nchunks = (nvalid + 31) >> 5;
   f32x4 cV = f32x4{0.f, 0.f, 0.f, 0.f}, cK = f32x4{0.f, 0.f, 0.f, 0.f};   // column sums of dV / dK over the keys (this lane's keys)
@@ -520,7 +535,7 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
           for (int r = 0; r < 4; ++r) {
             const int q = qt * AT + 32 * w + 16 * f + 4 * (lane >> 4) + r;
             float pr = 0.f, mult = 1.0f;
-            if (key < P.Tk && q < P.Tq) pr = __expf(sS[k4][f][r] * P.scale + mk - lse4[qt][f][r]);
+            if (key < P.Tk && q < P.Tq) pr = __expf(sS[k4][f][r] * score_scale + mk - lse4[qt][f][r]);
             // element index ((g heads + h) Tq + q) Tk + key = a wave-uniform 64-bit base + a small 24-bit product: no
             // 64-bit vector multiply per element (integer multiplies are quarter rate; the kernel is VALU-bound)
             if (P.p > 0.f) mult = dropout_mult(P.seed, drop_base + (__umul24((unsigned)q, (unsigned)P.Tk) + (unsigned)key), P.p, inv_keep);

@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnK P) {
           if (a.bias) s += a.bias[(((int64_t)g2 * a.heads + h) * a.R + r) * T + t];
           const bool filled = a.causal && t > r;
           if (filled) s = -1e4f;
-          const float pr = __expf(s - lse_r);
+          // (a row whose every key carries the hard finfo.min mask: its logsumexp IS finfo.min -- log T is absorbed -- and the
+          //  probabilities are uniform, as torch's softmax gives them)
+          const float pr = lse_r <= -1e30f ? 1.0f / (float)T : __expf(s - lse_r);
           float mult = 1.0f;
           if (a.dropout_p > 0.f)
             mult = dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * a.R + r) * T + t, a.dropout_p, inv_keep);

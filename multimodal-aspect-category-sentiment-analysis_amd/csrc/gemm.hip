@@ -9,23 +9,6 @@
 //                        shapes (classifier N=4, box WG 64->8 ...).
 #include "common.h"
 #include <cstdio>
-#include <cstdlib>
-#include <mutex>
-#include <unordered_map>
-
-// Diagnostic build only (make timing -> tools/bin/timing/libfcmf_hip.so): wave 0 of workgroup 0 stamps the
-// phases of its first work items with the 100 MHz real-time counter.  No stamp exists in the product build.
-#ifdef FCMF_GEMM_TIMING
-__device__ unsigned long long* g_stamp_buf = nullptr;
-extern "C" void fcmf_gemm_timing_buffer(void* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)); }
-#define FCMF_STAMP(k)                                                                                   \
-  do {                                                                                                  \
-    if (blockIdx.x == 0 && threadIdx.x == 0 && g_stamp_buf && stamp_item < 16)                          \
-      g_stamp_buf[stamp_item * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                             \
-  } while (0)
-#else
-#define FCMF_STAMP(k) do {} while (0)
-#endif
 
 struct GemmParams {
   const void* A; const void* B; void* C; const float* bias; void* aux;
@@ -143,6 +126,32 @@ __device__ __forceinline__ unsigned dma_voffset(int wave, int j, int lane, int64
   }
 }
 
+
+// ---- LDS-DMA issued from inline asm (kernels with a TRANSPOSED operand) ---------------------------------------------------
+// hipcc (ROCm 7.2) treats a compiler-visible LDS-DMA (`__builtin_amdgcn_raw_ptr_buffer_load_lds`) as a pending LDS store and
+// puts `s_waitcnt vmcnt(0)` in front of every `__builtin_amdgcn_ds_read_tr16_b64` that follows it -- not in front of plain
+// `ds_read_b128` fragment loads.  In the main loop that wait sat between the DMA of k-tile t+3 and the transposed fragment
+// reads of k-tile t: the whole prefetch pipeline drained once per k-tile, and the weight-gradient kernel (dW = dY^T X, both
+// operands transposed) ran one DMA round trip per k-tile (~1.0 us, 1700 cycles against 1024 cycles of MFMA; round-2
+// profiles/r02_gemm_k64.txt "TN").  An asm statement without outputs is register-safe (cdna_hip_programming.md section 5.7,
+// item 1); ordering is the kernel's own counted vmcnt + barrier, exactly as for the builtin.  M0 (the LDS destination) is
+// written in the statement that reads it, one wait state ahead of the load.
+__device__ __forceinline__ u32x4 rsrc_words(const void* p, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)reinterpret_cast<unsigned long long>((__attribute__((address_space(3))) const char*)p);
+}
+__device__ __forceinline__ void dma16_asm(const u32x4& rsrc, unsigned lds_dst, unsigned voffset, unsigned soffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_dst), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+__device__ __forceinline__ void dma16_asm0(const u32x4& rsrc, unsigned lds_dst, unsigned voffset) {   // soffset = 0
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_dst), "v"(voffset), "s"(rsrc) : "memory");
+}
+
 template <bool TR>
 __device__ __forceinline__ bf16x8 read_frag(const char* lds, int x0, int lane) {
   if (!TR) {
@@ -201,15 +210,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   const unsigned a_step = A_TR ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
   const unsigned b_step = B_TR ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
 
+  constexpr bool ASM_DMA = A_TR || B_TR;    // (see dma16_asm: transposed fragment reads must not see a compiler-visible LDS-DMA)
+  [[maybe_unused]] const u32x4 wA = rsrc_words(p.A, p.a_bytes), wB = rsrc_words(p.B, p.b_bytes);
   auto issue = [&](int t) {   // k-tile index relative to kt_begin -> ring stage t & 3
     char* st = smem + (t & (NSTAGE - 1)) * STAGE_BYTES + (wave * 2) * 1024;
     const unsigned ka = (unsigned)(kt_begin + t) * a_step, kb = (unsigned)(kt_begin + t) * b_step;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j] + ka, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j], ka, 0, 0);
-      if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + TILE_BYTES + j * 1024), 16, vb[j] + kb, 0, 0, 0);
-      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + TILE_BYTES + j * 1024), 16, vb[j], kb, 0, 0);
+      if constexpr (ASM_DMA) {
+        if (A_TR) dma16_asm0(wA, lds_addr_of(st + j * 1024), va[j] + ka);
+        else      dma16_asm(wA, lds_addr_of(st + j * 1024), va[j], ka);
+        if (B_TR) dma16_asm0(wB, lds_addr_of(st + TILE_BYTES + j * 1024), vb[j] + kb);
+        else      dma16_asm(wB, lds_addr_of(st + TILE_BYTES + j * 1024), vb[j], kb);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j], ka, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + TILE_BYTES + j * 1024), 16, vb[j], kb, 0, 0);
+      }
     }
   };
 
@@ -350,13 +366,6 @@ __device__ __forceinline__ int swz_row64(int r) { return (r >> 1) & 7; }
 template <bool TR, int KB>
 __device__ __forceinline__ unsigned dma_voffset_t(int piece, int lane, int64_t ld, int x0, int xdim) {
   const int q = piece * 64 + lane;             // 16-B slot inside the operand tile
-#ifdef FCMF_GEMM_ABLATE_LINE   // diagnostic (DMA stream alone): K-contiguous operands fetched as 128 rows x 128 B (whole cache
-  if (!TR && KB == 32) {        // lines, each once) per k-tile instead of 256 rows x 64 B; odd k-tiles take rows 128..255
-    const int row = q >> 3, c = q & 7;
-    if (x0 + row >= xdim) return 0x80000000u;
-    return (unsigned)(((int64_t)(x0 + row) * ld + c * 8) * 2);
-  }
-#endif
   if (!TR && KB == 32) {
     const int row = q >> 2, c = (q & 3) ^ swz_row(row);
     if (x0 + row >= xdim) return 0x80000000u;
@@ -424,6 +433,8 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   const int nk_total = (p.K + KB - 1) / KB;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  constexpr bool ASM_DMA = A_TR || B_TR;    // (see dma16_asm: transposed fragment reads must not see a compiler-visible LDS-DMA)
+  [[maybe_unused]] const u32x4 wA = rsrc_words(p.A, p.a_bytes), wB = rsrc_words(p.B, p.b_bytes);
   const unsigned a_step = A_TR ? (unsigned)(KB * p.lda * 2) : (unsigned)(KB * 2);
   const unsigned b_step = B_TR ? (unsigned)(KB * p.ldb * 2) : (unsigned)(KB * 2);
   // Per-lane LDS offsets are computed ONCE; fragment f of a K-contiguous operand is a constant 1 KiB
@@ -483,11 +494,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   struct Src { unsigned a[A_PIECES], b[B_PIECES]; };
   auto sources = [&](const Item& w) -> Src {
     Src r;
-#ifdef FCMF_GEMM_ABLATE_SRC
-    for (int j = 0; j < A_PIECES; ++j) r.a[j] = (unsigned)lane * 16u;
-    for (int j = 0; j < B_PIECES; ++j) r.b[j] = (unsigned)lane * 16u;
-    return r;
-#endif
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR, KB>(a_piece0 + j, lane, p.lda, w.i0, p.M);
 #pragma unroll
@@ -496,35 +502,30 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   };
   // DMA of k-tile t of item w: A tile to sa and / or B tile to sb (nullptr = skip)
   auto issue_ab = [&](const Item& w, const Src& src, int t, char* sa, char* sb) {
-#ifdef FCMF_GEMM_ABLATE_DMA      // diagnostic build: no global->LDS traffic (the ring holds whatever it held)
-    return;
-#endif
-#ifdef FCMF_GEMM_ABLATE_SRC      // diagnostic build: every DMA piece re-reads the SAME first 1 KiB of its operand (L1 hits)
-    const unsigned ka = 0, kb = 0;
-#else
-#ifdef FCMF_GEMM_ABLATE_LINE
-    const int tt = w.kt_begin + t;
-    const unsigned ka = A_TR ? (unsigned)tt * a_step : (unsigned)(tt >> 1) * 128u + (unsigned)(tt & 1) * 128u * (unsigned)p.lda * 2u;
-    const unsigned kb = B_TR ? (unsigned)tt * b_step : (unsigned)(tt >> 1) * 128u + (unsigned)(tt & 1) * 128u * (unsigned)p.ldb * 2u;
-#else
     const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
-#endif
-#endif
     if (sa) {
 #pragma unroll
       for (int j = 0; j < A_PIECES; ++j) {
         if (MI != 8 && j >= na_pieces) break;
         char* d = sa + (a_piece0 + j) * 1024;
-        if (A_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j] + ka, 0, 0, 0);
-        else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j], ka, 0, 0);
+        if constexpr (ASM_DMA) {
+          if (A_TR) dma16_asm0(wA, lds_addr_of(d), src.a[j] + ka);
+          else      dma16_asm(wA, lds_addr_of(d), src.a[j], ka);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)d, 16, src.a[j], ka, 0, 0);
+        }
       }
     }
     if (sb) {
 #pragma unroll
       for (int j = 0; j < B_PIECES; ++j) {
         char* d = sb + (wave * B_PIECES + j) * 1024;
-        if (B_TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, src.b[j] + kb, 0, 0, 0);
-        else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, src.b[j], kb, 0, 0);
+        if constexpr (ASM_DMA) {
+          if (B_TR) dma16_asm0(wB, lds_addr_of(d), src.b[j] + kb);
+          else      dma16_asm(wB, lds_addr_of(d), src.b[j], kb);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)d, 16, src.b[j], kb, 0, 0);
+        }
       }
     }
   };
@@ -545,9 +546,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 #pragma unroll
   for (int j = 0; j < A_PIECES; ++j) asm volatile("" : "+v"(src.a[j]), "+v"(src.b[j]));   // materialised here, not re-derived per k-tile
   const int i0 = w.i0, j0 = w.j0, nkt = w.nkt;
-  [[maybe_unused]] const int stamp_item = (item - slot) / nblk;
-  [[maybe_unused]] unsigned long long stamp_cyc0 = 0;
-  FCMF_STAMP(0);
   // Issue schedule: tiles 0, 1, 2 before the loop (or already in flight from the previous epilogue), tile t + 3
   // after barrier t.  Own DMAs of tile t have landed once at most the two younger tiles (4 DMAs each) are
   // outstanding: loads retire in order, and stores of the previous epilogue that are still in flight only
@@ -564,11 +562,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       return;
     }
-#ifdef FCMF_GEMM_DEPTH2        // diagnostic build: two k-tiles in flight instead of three (prefetch-depth sensitivity)
-    if (younger >= 1) { if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-#endif
     if (younger >= 2) { if (PT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else if (younger == 1) { if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -581,10 +574,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         issue_ab(w, src, a_next, slot_at(2 * (a_next - t)), nullptr);
       return;
     }
-#ifdef FCMF_GEMM_DEPTH2
-    if (t + 2 < nkt) issue(w, src, t + 2, t + 2);
-    return;
-#endif
     if (t + 3 < nkt) issue(w, src, t + 3, t + 3);
   };
 
@@ -594,14 +583,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 #pragma unroll
     for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 fa[MI], fb[4];
-#ifdef FCMF_GEMM_ABLATE_FRAGS
-  for (int f = 0; f < MI; ++f) fa[f] = bf16x8{};
-  for (int f = 0; f < 4; ++f) fb[f] = bf16x8{};
-#endif
   auto load_frags = [&](int t, int h) {     // h: 32-deep half of the k-tile (always 0 at KB = 32)
-#ifdef FCMF_GEMM_ABLATE_FRAGS    // diagnostic build (with ABLATE_MMA): no fragment reads either -> the DMA stream alone
-    return;
-#endif
     const char* sa = RING5 ? slot_at(0) : stage_at(t);
     const char* sb = RING5 ? slot_at(1) : stage_at(t) + A_TILE_BYTES;
 #pragma unroll
@@ -610,13 +592,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     for (int f = 0; f < MI; ++f) fa[f] = frag_a(sa, f, h);
   };
   auto mma = [&]() {
-#ifdef FCMF_GEMM_ABLATE_MMA      // diagnostic build: feed only (fragments stay live, no matrix instructions)
-#pragma unroll
-    for (int fi = 0; fi < MI; ++fi) asm volatile("" :: "v"(fa[fi]));
-#pragma unroll
-    for (int fj = 0; fj < 4; ++fj) asm volatile("" :: "v"(fb[fj]));
-    return;
-#endif
 #pragma unroll
     for (int fi = 0; fi < MI; ++fi)
 #pragma unroll
@@ -630,9 +605,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     else issue(w, src, 0, 0);
     if constexpr (KB == 32) {
       if (1 < nkt) issue(w, src, 1, 1);
-#ifndef FCMF_GEMM_DEPTH2
       if (2 < nkt) issue(w, src, 2, 2);
-#endif
     }
   }
   // aux operand of the epilogue (gelu' argument / residual), row layout: 16 B per lane, 8 rows of the wave's
@@ -666,10 +639,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     for (int t = 0; t < nkt; ++t) {
       wait_landed(t, IntTag<4>{});
       __builtin_amdgcn_s_barrier();            // tile t visible; the stage of tile t-1 is no longer read
-#ifdef FCMF_GEMM_TIMING
-      if (t == 0) { FCMF_STAMP(1); stamp_cyc0 = __builtin_readcyclecounter(); }
-      if (t == 8 * 32 / KB) FCMF_STAMP(6);
-#endif
       issue_after_barrier(t);
       if constexpr (EARLY_AUX) {
         if (t == nkt - 1) { load_aux(0); load_aux(1); }
@@ -702,10 +671,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 #pragma unroll
     for (int rnd = EARLY_AUX ? 2 : 0; rnd < (EARLY_AUX ? NRND : 2); ++rnd) load_aux(rnd);
   }
-  FCMF_STAMP(2);
-#ifdef FCMF_GEMM_TIMING   // slot 7: shader-clock cycles of the main loop (s_memtime) -> the clock the loop ran at
-  if (blockIdx.x == 0 && threadIdx.x == 0 && g_stamp_buf && stamp_item < 16) g_stamp_buf[stamp_item * 8 + 7] = __builtin_readcyclecounter() - stamp_cyc0;
-#endif
 
   TC* C = reinterpret_cast<TC*>(p.C);
   if constexpr (sizeof(TC) == 2) {
@@ -748,13 +713,10 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         else issue(wnx, snx, 0, nkt);
         if constexpr (KB == 32) {
           if (1 < wnx.nkt) issue(wnx, snx, 1, nkt + 1);
-#ifndef FCMF_GEMM_DEPTH2
           if (2 < wnx.nkt) issue(wnx, snx, 2, nkt + 2);
-#endif
         }
       }
     }
-    FCMF_STAMP(3);
     if (p.bias) {
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) {
@@ -819,7 +781,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         store_round(rnd, rC, p.colsum != nullptr);
         __builtin_amdgcn_sched_barrier(0);
       }
-      FCMF_STAMP(4);
     } else {
       const bool two_pass = (EPI == FCMF_EPI_GELU) && p.aux != nullptr;
       // accumulators -> finished bf16 values (straight-line code; the accumulator registers die as it goes).
@@ -838,7 +799,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         }
         __builtin_amdgcn_sched_barrier(0);   // one fragment row at a time: short live ranges
       }
-      FCMF_STAMP(4);
       auto write_out = [&](const auto& o, const __amdgpu_buffer_rsrc_t& rD, bool sums) __attribute__((always_inline)) {
 #pragma unroll
         for (int rnd = 0; rnd < MI / 2; ++rnd) {
@@ -957,7 +917,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     }
   }
   if constexpr (!RING5) base = (base + nkt) & (TNST - 1);
-  FCMF_STAMP(5);
   }  // work items
 }
 
@@ -1187,52 +1146,63 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-// caller-owned split-K workspaces, one per stream (a GEMM on a stream without one uses float atomics)
-struct Workspace { float* ptr; int64_t bytes; };
-struct WsKey {
-  int device; void* stream;
-  bool operator==(const WsKey& o) const { return device == o.device && stream == o.stream; }
+// ---- explicit GEMM context ------------------------------------------------------------------------------------------
+// Everything fcmf_gemm uses beyond its arguments lives in a caller-owned context (include/fcmf_hip.h): the split-K
+// workspace, the tuning knobs of benchmarks / tests and the name of the kernel the last call dispatched.  The library
+// itself holds no mutable process-global state; a NULL context means defaults (no workspace: float atomics for split-K).
+struct fcmf_gemm_ctx {
+  float* ws = nullptr;          // split-K partial tiles (device memory owned by the caller)
+  int64_t ws_bytes = 0;
+  int force_tile = 0;           // 0 = heuristic, 128 / 192 / 256 = forced kernel
+  int kb64 = 1;                 // 64-deep k-tiles where they apply
+  int num_cus = 256;            // workgroups of the persistent kernels (MI355X: 8 XCDs x 32 CUs, one 160-KiB-LDS workgroup per CU)
+  int64_t nt_min_bytes = 0;     // bf16 outputs of at least this many bytes leave with nontemporal stores
+  char last_kernel[96] = "";
 };
-struct WsKeyHash {
-  size_t operator()(const WsKey& k) const { return std::hash<void*>()(k.stream) ^ (std::hash<int>()(k.device) * 0x9E3779B97F4A7C15ull); }
-};
-static std::mutex g_ws_mutex;
-static std::unordered_map<WsKey, Workspace, WsKeyHash> g_ws;   // keyed by (current device, stream): stream 0 exists on every device
-static WsKey ws_key(void* stream) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  return WsKey{dev, stream};
-}
-extern "C" int fcmf_gemm_set_workspace(void* ptr, int64_t bytes, void* stream) {
-  std::lock_guard<std::mutex> lock(g_ws_mutex);
-  if (!ptr || bytes <= 0) g_ws.erase(ws_key(stream));
-  else g_ws[ws_key(stream)] = Workspace{reinterpret_cast<float*>(ptr), bytes};
+static const fcmf_gemm_ctx g_default_ctx;    // (const: the defaults of a NULL context)
+
+extern "C" int fcmf_gemm_ctx_create(fcmf_gemm_ctx** ctx) {
+  if (!ctx) return FCMF_ERR_ARG;
+  *ctx = new fcmf_gemm_ctx();
   return FCMF_OK;
 }
+extern "C" int fcmf_gemm_ctx_destroy(fcmf_gemm_ctx* ctx) {
+  delete ctx;
+  return FCMF_OK;
+}
+extern "C" int fcmf_gemm_ctx_set_workspace(fcmf_gemm_ctx* ctx, void* ptr, int64_t bytes) {
+  if (!ctx || bytes < 0 || (!ptr && bytes > 0)) return FCMF_ERR_ARG;
+  ctx->ws = reinterpret_cast<float*>(ptr);
+  ctx->ws_bytes = ptr ? bytes : 0;
+  return FCMF_OK;
+}
+extern "C" int fcmf_gemm_ctx_tune(fcmf_gemm_ctx* ctx, int force_tile, int kb, int num_cus, int64_t nt_min_bytes) {
+  if (!ctx) return FCMF_ERR_ARG;
+  if (force_tile >= 0) {
+    if (force_tile != 0 && force_tile != 128 && force_tile != 192 && force_tile != 256) return FCMF_ERR_ARG;
+    ctx->force_tile = force_tile;
+  }
+  if (kb >= 0) {
+    if (kb != 32 && kb != 64) return FCMF_ERR_ARG;
+    ctx->kb64 = kb == 64;
+  }
+  if (num_cus >= 0) {
+    if (num_cus < 8 || num_cus > 256) return FCMF_ERR_ARG;
+    ctx->num_cus = num_cus;
+  }
+  if (nt_min_bytes >= 0) ctx->nt_min_bytes = nt_min_bytes;
+  return FCMF_OK;
+}
+extern "C" const char* fcmf_gemm_ctx_last_kernel(const fcmf_gemm_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
 
-// MI355X: 8 XCDs x 32 CUs; one persistent 160-KiB-LDS workgroup per CU.  FCMF_GEMM_CUS=<n> (read once) makes the
-// persistent GEMMs use n workgroups, leaving CUs to kernels that run beside them (RCCL in data-parallel runs).
-static int g_num_cus = [] {
-  const char* e = getenv("FCMF_GEMM_CUS");
-  const int n = e ? atoi(e) : 256;
-  return n >= 8 && n <= 256 ? n : 256;
-}();
-// name of the kernel the last fcmf_gemm call of this thread dispatched (benchmarks attribute time by it)
-static thread_local char g_last_kernel[96] = "";
-extern "C" const char* fcmf_gemm_last_kernel(void) { return g_last_kernel; }
-static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced kernel (benchmarks, tests)
-extern "C" void fcmf_gemm_force_tile(int tile) { g_force_tile = tile; }
-// bf16 outputs of at least this many bytes leave the persistent kernels with nontemporal stores (FCMF_GEMM_NT_MIN_MB, read once)
-static int64_t g_nt_min_bytes = [] { const char* e = getenv("FCMF_GEMM_NT_MIN_MB"); return (int64_t)(e ? atoi(e) : 0) << 20; }();
-// FCMF_GEMM_KB=32 (read once) keeps the 32-deep k-tiles everywhere (A/B measurements of the 64-deep variant);
-// fcmf_gemm_force_kb(32) does the same at run time (tests: both depths multiply in the same order -> identical bits)
-static int g_kb64 = [] { const char* e = getenv("FCMF_GEMM_KB"); return !(e && atoi(e) == 32); }();
-extern "C" void fcmf_gemm_force_kb(int kb) { g_kb64 = kb != 32; }
-
-extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum, int M,
-                         int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
+extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
+                         int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
                          int out_dtype, int epilogue, int accumulate, void* stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0) return FCMF_ERR_ARG;
+  const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
+  char name_sink[96];
+  char* const last_kernel = ctx ? ctx->last_kernel : name_sink;
+  constexpr size_t NAME = sizeof(name_sink);
   if (M == 0 || N == 0) return FCMF_OK;
   if (accumulate && out_dtype != FCMF_F32) return FCMF_ERR_ARG;
   if ((epilogue == FCMF_EPI_DGELU || epilogue == FCMF_EPI_DTANH || epilogue == FCMF_EPI_ADD) && !aux) return FCMF_ERR_ARG;
@@ -1267,10 +1237,10 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     // fragment-layout atomics from K = 1024 up -- 25 vs 97 us at 768x768x2048)
     bool large = tile_ok && M >= 256 && N >= 256 &&
                  ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && K >= 512));
-    if (g_force_tile == 128) large = false;
-    if (g_force_tile == 256 || g_force_tile == 192) large = tile_ok;
+    if (cfg.force_tile == 128) large = false;
+    if (cfg.force_tile == 256 || cfg.force_tile == 192) large = tile_ok;
     if (large) {
-      const int slots = g_num_cus;
+      const int slots = cfg.num_cus;
       // block tile rows: 256, or 192 where that removes a nearly empty last round (cost model: rounds x
       // (k-loop time scaled by the tile rows + a fixed per-tile cost of ~8 k-tiles))
       int tm = 256;
@@ -1281,11 +1251,11 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
         };
         if (cost(192) < 0.97 * cost(256)) tm = 192;
       }
-      if (g_force_tile == 192 && !trans_a && out_dtype == FCMF_BF16 && !accumulate) tm = 192;
+      if (cfg.force_tile == 192 && !trans_a && out_dtype == FCMF_BF16 && !accumulate) tm = 192;
       const int tiles_l = ((M + tm - 1) / tm) * ((N + GB - 1) / GB);
       // 64-deep k-tiles where both operands are K-contiguous (whole-line DMA), the output is bf16 and K allows it
       // (weight gradients -- token-major operands, 512-B DMA rows already -- measured 4-8 % SLOWER on 64-deep k-tiles)
-      const int kb = (g_kb64 && !trans_a && !trans_b && out_dtype == FCMF_BF16 && !accumulate && K % 64 == 0) ? 64 : 32;
+      const int kb = (cfg.kb64 && !trans_a && !trans_b && out_dtype == FCMF_BF16 && !accumulate && K % 64 == 0) ? 64 : 32;
       const int nk = (K + kb - 1) / kb;      // (shadows the 32-deep count above: the kernel counts k-tiles of ITS depth)
       int ksplit = 1;
       if (accumulate && epilogue == FCMF_EPI_NONE && tiles_l < slots) {
@@ -1300,17 +1270,13 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
       p.total_items = tiles_l * p.ksplit;
       dim3 grid(p.total_items < slots ? p.total_items : slots);
       p.ws = nullptr;
-      p.nt_out = out_dtype == FCMF_BF16 && (int64_t)M * N * 2 >= g_nt_min_bytes;
-      if (p.ksplit > 1) {
-        std::lock_guard<std::mutex> lock(g_ws_mutex);
-        auto it = g_ws.find(ws_key(stream));
-        if (it != g_ws.end() && it->second.bytes >= (int64_t)p.ksplit * M * N * 4) p.ws = it->second.ptr;
-      }
+      p.nt_out = out_dtype == FCMF_BF16 && (int64_t)M * N * 2 >= cfg.nt_min_bytes;
+      if (p.ksplit > 1 && cfg.ws && cfg.ws_bytes >= (int64_t)p.ksplit * M * N * 4) p.ws = cfg.ws;
       {
         static const char* const epi_names[] = {"NONE", "GELU", "TANH", "DGELU", "DTANH", "ADD"};
-        if (kb == 64) snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile%dk64_kernel<%s>", tm, epi_names[epilogue]);
-        else if (tm == 192) snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile192_kernel<%d,%s>", trans_b, epi_names[epilogue]);
-        else snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_tile256_kernel<%d,%d,%s,%s>", trans_a, trans_b, out_dtype == FCMF_F32 ? "f32" : "bf16", epi_names[epilogue]);
+        if (kb == 64) snprintf(last_kernel, NAME, "gemm_bf16_tile%dk64_kernel<%s>", tm, epi_names[epilogue]);
+        else if (tm == 192) snprintf(last_kernel, NAME, "gemm_bf16_tile192_kernel<%d,%s>", trans_b, epi_names[epilogue]);
+        else snprintf(last_kernel, NAME, "gemm_bf16_tile256_kernel<%d,%d,%s,%s>", trans_a, trans_b, out_dtype == FCMF_F32 ? "f32" : "bf16", epi_names[epilogue]);
       }
       int rc;
       if (!trans_a && !trans_b) rc = launch_bf16_tile<false, false>(p, out_dtype, grid, st, tm, kb);
@@ -1341,7 +1307,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
     p.ktiles_per_split = (nk + ksplit - 1) / ksplit;
     p.ksplit = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
     dim3 grid(tiles, 1, p.ksplit);
-    snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_bf16_kernel<%d,%d,%s>", trans_a, trans_b, out_dtype == FCMF_F32 ? "f32" : "bf16");
+    snprintf(last_kernel, NAME, "gemm_bf16_kernel<%d,%d,%s>", trans_a, trans_b, out_dtype == FCMF_F32 ? "f32" : "bf16");
     if (!trans_a && !trans_b) return launch_bf16<false, false>(p, out_dtype, grid, st);
     if (!trans_a && trans_b) return launch_bf16<false, true>(p, out_dtype, grid, st);
     if (trans_a && !trans_b) return launch_bf16<true, false>(p, out_dtype, grid, st);
@@ -1351,7 +1317,7 @@ extern "C" int fcmf_gemm(const void* A, const void* B, void* C, const float* bia
                   trans_a ? 1 : lda, trans_a ? lda : 1, trans_b ? 1 : ldb, trans_b ? ldb : 1, ldc,
                   epilogue, accumulate, colsum};
   dim3 grid((N + 63) / 64, (M + 63) / 64);
-  snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_generic_kernel");
+  snprintf(last_kernel, NAME, "gemm_generic_kernel");
   if (in_dtype == FCMF_F32 && out_dtype == FCMF_F32)
     hipLaunchKernelGGL((gemm_generic_kernel<float, float>), grid, dim3(256), 0, st, g);
   else if (in_dtype == FCMF_BF16 && out_dtype == FCMF_BF16)

@@ -353,8 +353,8 @@ static int grid_for(int64_t n, int per) {
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
-extern "C" int fcmf_abi_version(void) { return 2; }   // 2: fcmf_attn_mfma_bwd gained `colsum`
-extern "C" const char* fcmf_build_info(void) { return "libfcmf_hip gfx950 (CDNA4, wave64) abi 2"; }
+extern "C" int fcmf_abi_version(void) { return 3; }   // 2: fcmf_attn_mfma_bwd gained `colsum`; 3: explicit GEMM context (fcmf_gemm takes a ctx), fcmf_dp_*
+extern "C" const char* fcmf_build_info(void) { return "libfcmf_hip gfx950 (CDNA4, wave64) abi 3"; }
 
 extern "C" int fcmf_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, float* loss_rows, float* nvalid, int n,
                              int C, int64_t ignore_index, int dtype, void* stream) {

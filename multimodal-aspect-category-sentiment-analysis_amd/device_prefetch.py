@@ -1,0 +1,111 @@
+"""Host -> HBM hand-off of the batch producer: the NEXT batch is pinned and copied on a dedicated HIP stream while the
+current step computes, so the PCIe transfer leaves the critical path of the step.
+
+The reference moves every batch synchronously at the top of the step (`batch = tuple(t.to(device) ...)`,
+run_multimodal_fcmf.py:440-446, run_pretraining_fcmf.py:297-303) from pageable DataLoader memory, then converts the float64
+ROI crops on the device (`roi_img_features.float()`, :447).  A B=64 batch of precomputed features is 312 MB in float32
+(156 MB from the bf16 `FeatureCache`): 6-24 ms of a 42 ms step when it is not overlapped.
+
+  * a worker thread pulls batches from the loader and pins them (page-locking is a host memcpy: it must not sit in the
+    thread that launches kernels);
+  * the main thread issues the `non_blocking` copies of batch i+1 on `copy_stream` right after handing out batch i, and
+    makes the compute stream wait for batch i's copy event only when batch i is about to be used;
+  * dtype hand-off on the device, on the copy stream: float64 pixel crops -> float32 (what the reference's `.float()` does;
+    the ROI BOXES stay float64 -- the parity mode does the box geometry in float64, roi_modeling.py:79-138), bf16 features
+    stay bf16 (the MFMA path consumes them as they are);
+  * tensors are `record_stream`ed on the compute stream: the caching allocator will not recycle them while the step runs.
+"""
+import queue
+import threading
+
+import torch
+
+
+class DevicePrefetcher:
+    def __init__(self, loader, device, depth=2, float64_pixels_to_float32=True):
+        """loader: any iterable of tuples / dicts of CPU tensors (DataLoader, SyntheticBatches, a generator);
+        depth: how many batches may wait pinned on the host"""
+        self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
+        self.f64_to_f32 = float64_pixels_to_float32
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.bytes_copied = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    # ---- host side (worker thread) ---------------------------------------------------------------------------
+    @staticmethod
+    def _pin(x):
+        if torch.is_tensor(x) and not x.is_cuda and not x.is_pinned() and x.numel() > 0:
+            return x.contiguous().pin_memory()
+        return x
+
+    def _map(self, batch, fn):
+        if isinstance(batch, dict):
+            return {k: fn(v) for k, v in batch.items()}
+        if isinstance(batch, (tuple, list)):
+            return tuple(fn(v) for v in batch)
+        return fn(batch)
+
+    def _worker(self, q, stop):
+        try:
+            for batch in self.loader:
+                if stop.is_set():
+                    return
+                q.put(self._map(batch, self._pin))
+            q.put(StopIteration)
+        except BaseException as e:            # surfaces in the consumer, never swallowed
+            q.put(e)
+
+    # ---- device side (caller's thread) -----------------------------------------------------------------------
+    def _to_device(self, x):
+        if not torch.is_tensor(x):
+            return x
+        y = x.to(self.device, non_blocking=True)
+        self.bytes_copied += x.numel() * x.element_size()
+        # pixel crops [.., 3, H, W] arrive in float64 from the reference's dataset (vimacsa_dataset.py:175-199): float32 on
+        # the device, as the reference's `.float()`; 4-column box tensors keep their dtype
+        if self.f64_to_f32 and y.dtype == torch.float64 and y.dim() >= 4 and y.shape[-3] == 3:
+            y = y.float()
+        return y
+
+    def _upload(self, host):
+        with torch.cuda.stream(self.copy_stream):
+            dev = self._map(host, self._to_device)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        return dev, ev, host                  # (host: the pinned source must outlive the asynchronous copy)
+
+    def __iter__(self):
+        q, stop = queue.Queue(maxsize=self.depth), threading.Event()
+        t = threading.Thread(target=self._worker, args=(q, stop), daemon=True)
+        t.start()
+
+        def take():
+            item = q.get()
+            if item is StopIteration:
+                return None
+            if isinstance(item, BaseException):
+                raise item
+            return self._upload(item)
+        keep = []                             # pinned sources of copies that may still be in flight
+        try:
+            nxt = take()
+            while nxt is not None:
+                dev, ev, host = nxt
+                nxt = take()                  # batch i+1 starts travelling before batch i is consumed
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for v in (dev.values() if isinstance(dev, dict) else dev if isinstance(dev, tuple) else (dev,)):
+                    if torch.is_tensor(v):
+                        v.record_stream(cur)
+                keep.append((ev, host))
+                keep = [(e, h) for e, h in keep if not e.query()]
+                yield dev
+        finally:
+            stop.set()
+            while t.is_alive():               # unblock a worker stuck on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    t.join(timeout=0.05)

@@ -35,11 +35,12 @@ class AttnDesc(ctypes.Structure):
 SIGNATURES = {
     "fcmf_abi_version": [],
     "fcmf_build_info": [],
-    "fcmf_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp],
-    "fcmf_gemm_force_tile": [_i],
-    "fcmf_gemm_force_kb": [_i],
-    "fcmf_gemm_last_kernel": [],
-    "fcmf_gemm_set_workspace": [_vp, _i64, _vp],
+    "fcmf_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_gemm_ctx_create": [_c.POINTER(_vp)],
+    "fcmf_gemm_ctx_destroy": [_vp],
+    "fcmf_gemm_ctx_set_workspace": [_vp, _vp, _i64],
+    "fcmf_gemm_ctx_tune": [_vp, _i, _i, _i, _i64],
+    "fcmf_gemm_ctx_last_kernel": [_vp],
     "fcmf_colsum": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "fcmf_attn_small_fwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp],
     "fcmf_attn_small_bwd": [_c.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -106,8 +107,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args
-            fn.restype = (ctypes.c_char_p if name in ("fcmf_build_info", "fcmf_gemm_last_kernel") else
-                          None if name in ("fcmf_gemm_force_tile", "fcmf_gemm_force_kb") else
+            fn.restype = (ctypes.c_char_p if name in ("fcmf_build_info", "fcmf_gemm_ctx_last_kernel") else
                           ctypes.c_int64 if name in ("fcmf_add_ln_bwd_workspace", "fcmf_bn_stats_workspace") else ctypes.c_int)
         _lib = l
     return _lib
@@ -143,6 +143,55 @@ def stream():
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
+
+# ---- GEMM contexts: one per (device, stream), created on first use ---------------------------------------------------------
+SPLITK_WORKSPACE_BYTES = 96 << 20   # >= ksplit*M*N*4 of every weight-gradient GEMM of FCMF-base (66 MB for 768x768 x 28 splits)
+_gemm_ctx = {}
+_gemm_tuning = dict(tile=int(os.environ.get("FCMF_GEMM_TILE", "0")), kb=32 if os.environ.get("FCMF_GEMM_KB") == "32" else 64,
+                    cus=int(os.environ.get("FCMF_GEMM_CUS", "256")), nt_min_mb=int(os.environ.get("FCMF_GEMM_NT_MIN_MB", "0")))
+
+
+def _apply_tuning(h):
+    t = _gemm_tuning
+    check(lib().fcmf_gemm_ctx_tune(h, t["tile"], t["kb"], t["cus"], t["nt_min_mb"] << 20), "fcmf_gemm_ctx_tune")
+
+
+def gemm_ctx(workspace=False):
+    """the GEMM context of the current (device, stream): holds the split-K workspace (allocated when a weight-gradient GEMM
+    first asks for it), the tuning knobs and the name of the last kernel -- the library itself has no global state"""
+    key = (torch.cuda.current_device(), stream())
+    ent = _gemm_ctx.get(key)
+    if ent is None:
+        h = ctypes.c_void_p()
+        check(lib().fcmf_gemm_ctx_create(ctypes.byref(h)), "fcmf_gemm_ctx_create")
+        _apply_tuning(h)
+        ent = _gemm_ctx[key] = [h, None]
+    if workspace and ent[1] is None:
+        ent[1] = torch.empty(SPLITK_WORKSPACE_BYTES, dtype=torch.uint8, device=torch.device("cuda", key[0]))
+        check(lib().fcmf_gemm_ctx_set_workspace(ent[0], ent[1].data_ptr(), ent[1].numel()), "fcmf_gemm_ctx_set_workspace")
+    return ent[0]
+
+
+def set_gemm_tuning(tile=None, kb=None, cus=None, nt_min_mb=None):
+    """benchmark / test knobs (see fcmf_gemm_ctx_tune), applied to every existing and future context"""
+    for k, v in (("tile", tile), ("kb", kb), ("cus", cus), ("nt_min_mb", nt_min_mb)):
+        if v is not None:
+            _gemm_tuning[k] = int(v)
+    for h, _ in _gemm_ctx.values():
+        _apply_tuning(h)
+
+
+def drop_gemm_workspace():
+    """unregister and free the split-K workspaces (tests: the float-atomic path)"""
+    for ent in _gemm_ctx.values():
+        if ent[1] is not None:
+            check(lib().fcmf_gemm_ctx_set_workspace(ent[0], None, 0), "fcmf_gemm_ctx_set_workspace")
+            ent[1] = None
+
+
+def last_gemm_kernel():
+    return lib().fcmf_gemm_ctx_last_kernel(gemm_ctx()).decode()
 
 
 def require_cuda(*ts):

@@ -64,15 +64,17 @@ class GradArena:
         self.activate()
 
     @classmethod
-    def for_model(cls, model, skip=lambda name: "bert.cell.pooler" in name):
-        """arena over the model's live parameters; q|k|v parameters of every fused attention block adjacent"""
+    def for_model(cls, model, skip=lambda name: "bert.cell.pooler" in name, extra=()):
+        """arena over the model's live parameters; q|k|v parameters of every fused attention block adjacent.
+        extra: parameters of modules that run BEFORE the model in the step (the ResNet-152 extractors under
+        --fine_tune_cnn): their gradients are produced last in backward, so their slices follow the model's."""
         from .fused import QKVStorageMixin
         blocks = []
         for m in model.modules():
             if isinstance(m, QKVStorageMixin):
                 blocks.append([m.query.weight, m.key.weight, m.value.weight])
                 blocks.append([m.query.bias, m.key.bias, m.value.bias])
-        return cls([p for n, p in model.named_parameters() if not skip(n)], blocks)
+        return cls(list(extra) + [p for n, p in model.named_parameters() if not skip(n)], blocks)
 
     # ---- step protocol -------------------------------------------------------------------------
     def activate(self):

@@ -292,32 +292,17 @@ def gemm_trace_end():
     return [(name, fl, e0.elapsed_time(e1)) for name, fl, e0, e1 in tr]
 
 
-SPLITK_WORKSPACE_BYTES = 96 << 20   # >= ksplit*M*N*4 of every weight-gradient GEMM of FCMF-base (66 MB for 768x768 x 28 splits)
-_splitk_ws = {}
-
-
-def _ensure_splitk_workspace(device):
-    """one scratch buffer per (device, stream) for the split-K partial tiles of the weight-gradient GEMMs"""
-    st = H.stream()
-    key = (device.index, st)
-    if key not in _splitk_ws:
-        buf = torch.empty(SPLITK_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
-        H.check(H.lib().fcmf_gemm_set_workspace(H.ptr(buf), buf.numel(), st), "fcmf_gemm_set_workspace")
-        _splitk_ws[key] = buf
-
-
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI_NONE, acc=False, colsum=None):
     H.require_cuda(A, B, C)
-    if acc:
-        _ensure_splitk_workspace(C.device)
+    ctx = H.gemm_ctx(workspace=acc)       # (weight-gradient GEMMs: the context owns the split-K scratch of this stream)
     if _gemm_trace is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    H.check(H.lib().fcmf_gemm(H.ptr(A), H.ptr(B), H.ptr(C), H.ptr(bias), H.ptr(aux), H.ptr(colsum), M, N, K, lda, ldb, ldc,
+    H.check(H.lib().fcmf_gemm(ctx, H.ptr(A), H.ptr(B), H.ptr(C), H.ptr(bias), H.ptr(aux), H.ptr(colsum), M, N, K, lda, ldb, ldc,
                               int(ta), int(tb), H.dt(A), H.dt(C), epi, int(acc), H.stream()), "fcmf_gemm")
     if _gemm_trace is not None:
         e1.record()
-        _gemm_trace.append((H.lib().fcmf_gemm_last_kernel().decode(), 2.0 * M * N * K, e0, e1))
+        _gemm_trace.append((H.lib().fcmf_gemm_ctx_last_kernel(ctx).decode(), 2.0 * M * N * K, e0, e1))
 
 
 def colsum(X, M, N, ldx):

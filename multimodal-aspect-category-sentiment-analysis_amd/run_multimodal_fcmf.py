@@ -11,6 +11,11 @@ checkpoint dictionary and file names (:40-58,557-563), same torchrun environment
     :208-210 and :421);
   * --bf16 selects the MFMA path (bf16 activations, fp32 master weights, no loss scaler);
     --fp16 is accepted for compatibility and maps to --bf16.
+The ResNet-152 extractors are checkpointed next to the model under the reference's names
+(`seed_{seed}_resimg_model_{best,last}.pth`, `..._resroi_model_...`, :557-563) and restored on resume / for the test
+evaluation through the reference's path rewrites (:334-346, :588-598); after training, --do_eval runs the TEST-set
+evaluation of :567-694 and writes `test_results_fcmf.txt` + `test_predictions_formatted.txt` in the reference's format.
+Batches reach the GPU through `device_prefetch.DevicePrefetcher` (pinned host memory, copy stream, one batch ahead).
 Extra flags (not in the reference): --bf16, --synthetic_steps N (seeded synthetic batches with
 precomputed features: no dataset / tokenizer / torchvision needed), --precomputed_features.
 The host-side batch producer (vimacsa_dataset.MACSADataset, image decoding, ResNet-152 feature
@@ -34,6 +39,10 @@ from fcmf_framework import ops  # noqa: E402
 from fcmf_framework.dp import GradArena, GradReducer  # noqa: E402
 from fcmf_framework.fcmf_multimodal import FCMF  # noqa: E402
 from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup  # noqa: E402
+from device_prefetch import DevicePrefetcher  # noqa: E402
+
+
+POLARITY_MAP = {0: 'None', 1: 'Negative', 2: 'Neutral', 3: 'Positive'}      # reference :28
 
 
 def macro_f1(y_true, y_pred):
@@ -50,6 +59,32 @@ def save_model(path, model, optimizer, scheduler, epoch, best_score=0.0, scaler=
     if scaler is not None:
         ck['scaler_state_dict'] = scaler.state_dict()
     torch.save(ck, path)
+
+
+def companion_path(path, old, new):
+    """the reference's checkpoint-path rewrite (`checkpoint_path.replace("fcmf_model", "resimg_model")`, :334-335;
+    `best_path.replace("fcmf", "resimg")`, :588,594) applied to the FILE NAME only -- a directory called e.g.
+    `runs/fcmf/` must not be rewritten with it"""
+    d, f = os.path.split(path)
+    return os.path.join(d, f.replace(old, new))
+
+
+def load_resnets(path, resnet_img, resnet_roi, device, logger=None, old="fcmf_model", strict=True):
+    """restore the two extractors saved beside the model checkpoint `path` (reference :334-346 / :588-598)"""
+    loaded = []
+    for net, tag in ((resnet_img, "resimg"), (resnet_roi, "resroi")):
+        if net is None:
+            continue
+        q = companion_path(path, old, old.replace("fcmf", tag))
+        if os.path.exists(q):
+            ck = torch.load(q, map_location=device, weights_only=True)
+            net.load_state_dict(ck['model_state_dict'], strict=strict)
+            loaded.append(q)
+            if logger is not None:
+                logger.info("    Loading ResNet %s from: %s", tag, q)
+    if loaded:
+        ops.shadows.clear()                  # cached bf16 weight matrices of the trunk are stale
+    return loaded
 
 
 def build_parser():
@@ -138,8 +173,9 @@ class SyntheticBatches:
                 vis = synth.synth_crops(n, self.pixels, seed=self.seed + i).view(self.batch, self.ni, 3, self.pixels, self.pixels)
                 roi = synth.synth_crops(n * self.nr, self.pixels, seed=self.seed + i + 7919).view(
                     self.batch, self.ni, self.nr, 3, self.pixels, self.pixels).double()
+            texts = [f"synthetic review {self.seed + i}:{j}" for j in range(self.batch)]
             yield (vis, roi, b["roi_coors"], b["input_ids"], b["token_type_ids"],
-                   b["attention_mask"], b["added_attention_mask"], b["labels"], None)
+                   b["attention_mask"], b["added_attention_mask"], b["labels"], texts)
 
 
 def main(argv=None):
@@ -174,7 +210,7 @@ def main(argv=None):
     model = FCMF(pretrained_path=args.pretrained_hf_model, num_labels=args.num_polarity, num_imgs=args.num_imgs,
                  num_roi=args.num_rois, alpha=args.alpha)
     cfg = model.encoder.bert.cell.config
-    train_loader = dev_loader = None
+    train_loader = dev_loader = test_loader = None
     resnet_img = resnet_roi = None
     if args.synthetic_steps > 0:
         cfgd = dict(vocab_size=cfg.vocab_size, pad_token_id=cfg.pad_token_id)
@@ -186,6 +222,9 @@ def main(argv=None):
             dev_loader = SyntheticBatches(cfgd, max(1, args.synthetic_steps // 2), args.eval_batch_size,
                                           min(args.max_seq_length, 128, cfg.max_position_embeddings - 2),
                                           args.num_imgs, args.num_rois, len(ASPECT), args.seed + 77, pixels=args.synthetic_pixels)
+            test_loader = SyntheticBatches(cfgd, max(1, args.synthetic_steps // 2), args.eval_batch_size,
+                                           min(args.max_seq_length, 128, cfg.max_position_embeddings - 2),
+                                           args.num_imgs, args.num_rois, len(ASPECT), args.seed + 99, pixels=args.synthetic_pixels)
     elif args.do_train or args.do_eval:
         # real data: the reference's host-side producer (tokenizer, pandas, MACSADataset, torchvision ResNet-152)
         from transformers import AutoTokenizer
@@ -204,8 +243,11 @@ def main(argv=None):
         mk = lambda df: MACSADataset(df, tokenizer, args.image_dir, roi_df, dict_image_aspect, dict_roi_aspect, args.num_imgs, args.num_rois)
         train_ds, dev_ds = mk(pd.read_json(f'{args.data_dir}/train.json')), mk(pd.read_json(f'{args.data_dir}/dev.json'))
         sampler = DistributedSampler(train_ds) if world > 1 else RandomSampler(train_ds)     # shard ONCE
-        train_loader = DataLoader(train_ds, sampler=sampler, batch_size=args.train_batch_size)
-        dev_loader = DataLoader(dev_ds, sampler=SequentialSampler(dev_ds), batch_size=args.eval_batch_size)
+        train_loader = DataLoader(train_ds, sampler=sampler, batch_size=args.train_batch_size, pin_memory=True)
+        dev_loader = DataLoader(dev_ds, sampler=SequentialSampler(dev_ds), batch_size=args.eval_batch_size, pin_memory=True)
+        if args.do_eval and os.path.exists(f'{args.data_dir}/test.json'):                     # reference :570-573
+            test_ds = mk(pd.read_json(f'{args.data_dir}/test.json'))
+            test_loader = DataLoader(test_ds, sampler=SequentialSampler(test_ds), batch_size=args.eval_batch_size, pin_memory=True)
     pixels = (args.synthetic_steps > 0 and args.synthetic_pixels > 0) or \
              (args.synthetic_steps <= 0 and (args.do_train or args.do_eval) and not args.precomputed_features)
     if pixels:
@@ -252,6 +294,7 @@ def main(argv=None):
             scheduler.load_state_dict(ck['scheduler_state_dict'])
         start_epoch, max_f1 = ck['epoch'] + 1, ck.get('best_score', 0.0)
         ops.shadows.clear()
+        load_resnets(args.resume_from_checkpoint, resnet_img, resnet_roi, device, logger if master else None)   # reference :334-346
     elif args.pretrained_iaog_path and os.path.isfile(args.pretrained_iaog_path):
         sd = torch.load(args.pretrained_iaog_path, map_location='cpu', weights_only=True)['model_state_dict']
         model.load_state_dict({k: v for k, v in sd.items() if k.startswith('encoder.')}, strict=False)   # reference :385-391
@@ -273,8 +316,7 @@ def main(argv=None):
             if resnet_img is not None:
                 resnet_img.train(); resnet_roi.train()                # reference :431 (BatchNorm in batch-statistics mode)
             arena.zero()
-            for step, batch in enumerate(train_loader):
-                batch = tuple(t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
+            for step, batch in enumerate(DevicePrefetcher(train_loader, device)):     # next batch: pinned, on the copy stream
                 t_img, roi_img, roi_coors, ids, tts, ams, added, labels, _ = batch
                 vis, roi = features(t_img, roi_img)
                 logits = model.forward_aspects(input_ids=ids, token_type_ids=tts, attention_mask=ams, added_attention_mask=added,
@@ -305,13 +347,82 @@ def main(argv=None):
             if world > 1:
                 torch.distributed.barrier()
             if master:
-                if f1 > max_f1:
-                    max_f1 = f1
-                    save_model(f'{args.output_dir}/seed_{args.seed}_fcmf_model_best.pth', model, optimizer, scheduler, epoch, max_f1)
-                save_model(f'{args.output_dir}/seed_{args.seed}_fcmf_model_last.pth', model, optimizer, scheduler, epoch, max_f1)
+                tags = ['last'] + (['best'] if f1 > max_f1 else [])
+                max_f1 = max(max_f1, f1)
+                for tag in tags:                                      # reference :555-563: the model and BOTH extractors
+                    save_model(f'{args.output_dir}/seed_{args.seed}_fcmf_model_{tag}.pth', model, optimizer, scheduler, epoch, max_f1)
+                    if resnet_img is not None:
+                        save_model(f'{args.output_dir}/seed_{args.seed}_resimg_model_{tag}.pth', resnet_img, optimizer, scheduler, epoch)
+                        save_model(f'{args.output_dir}/seed_{args.seed}_resroi_model_{tag}.pth', resnet_roi, optimizer, scheduler, epoch)
+    # ---- 7. TEST EVALUATION (reference :567-694) ---------------------------------------------------------------------
+    if args.do_eval and master and test_loader is not None:
+        logger.info("===================== STARTING TEST EVALUATION =====================")
+        best_path = args.model_checkpoint if os.path.exists(args.model_checkpoint) else \
+            f'{args.output_dir}/seed_{args.seed}_fcmf_model_best.pth'
+        if os.path.exists(best_path):
+            logger.info("Loading Best Checkpoint from: %s", best_path)
+            ck = torch.load(best_path, map_location=device, weights_only=True)
+            model.load_state_dict(ck['model_state_dict'], strict=False)
+            ops.shadows.clear()
+            load_resnets(best_path, resnet_img, resnet_roi, device, logger, old="fcmf", strict=False)      # :588-598
+        else:
+            logger.warning("No best model found! Using current weights.")
+        if resnet_img is not None:
+            resnet_img.eval(); resnet_roi.eval()
+        test_evaluate(model, test_loader, device, features, ASPECT, args.output_dir, logger)
     arena.deactivate()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+@torch.no_grad()
+def test_evaluate(model, loader, device, features, aspects, output_dir, logger):
+    """test-set pass of the reference (:600-694): per-aspect precision / recall / macro-F1 into `test_results_fcmf.txt`, and
+    one block per review with the predicted and gold polarity of every aspect into `test_predictions_formatted.txt`"""
+    model.eval()
+    true = {a: [] for a in aspects}
+    pred = {a: [] for a in aspects}
+    formatted = []
+    for batch in DevicePrefetcher(loader, device):
+        t_img, roi_img, roi_coors, ids, tts, ams, added, labels, texts = batch
+        vis, roi = features(t_img, roi_img)
+        logits = model.forward_aspects(input_ids=ids, token_type_ids=tts, attention_mask=ams, added_attention_mask=added,
+                                       visual_embeds_att=vis, roi_embeds_att=roi, roi_coors=roi_coors)
+        p = logits.argmax(-1).cpu().numpy()
+        y = labels.cpu().numpy()
+        logs = [{"text": t, "aspects": {}} for t in (texts if texts is not None else [""] * len(p))]
+        for i, a in enumerate(aspects):
+            true[a].append(y[:, i]); pred[a].append(p[:, i])
+            for j, (pp, ll) in enumerate(zip(p[:, i], y[:, i])):
+                logs[j]["aspects"][a] = {"predict": POLARITY_MAP.get(int(pp), "Unknown"), "label": POLARITY_MAP.get(int(ll), "Unknown")}
+        formatted.extend(logs)
+    with open(os.path.join(output_dir, "test_results_fcmf.txt"), "w") as w:
+        w.write("***** Test results *****\n")
+        all_f1 = 0.0
+        for a in aspects:
+            precision, recall, f1 = macro_f1(np.concatenate(true[a]), np.concatenate(pred[a]))
+            all_f1 += f1
+            w.write(f"{a} - P: {precision:.4f}, R: {recall:.4f}, F1: {f1:.4f}\n")
+            logger.info("%s - F1: %.4f", a, f1)
+        avg_f1 = all_f1 / len(aspects)
+        w.write(f"Average F1: {avg_f1:.4f}\n")
+        logger.info("Average F1: %.4f", avg_f1)
+    log_path = f"{output_dir}/test_predictions_formatted.txt"
+    with open(log_path, "w", encoding="utf-8") as f:
+        f.write("TEST DETAILED PREDICTIONS\n")
+        f.write(f"Average Macro F1: {avg_f1:.4f}\n")
+        f.write("=" * 50 + "\n\n")
+        for i, sample in enumerate(formatted):
+            f.write("{\n")
+            f.write(f"Sentence {i}: {sample['text']}\n")
+            for a in aspects:
+                res = sample['aspects'].get(a, {'predict': 'N/A', 'label': 'N/A'})
+                f.write(f"{a}:\n")
+                f.write(f"   predict: {res['predict']}\n")
+                f.write(f"   label:   {res['label']}\n")
+            f.write("}\n")
+    logger.info("Formatted predictions saved to %s", log_path)
+    return avg_f1
 
 
 @torch.no_grad()
@@ -319,8 +430,7 @@ def evaluate(model, loader, device, features, num_aspects, logger):
     """dev-set macro-F1 averaged over aspects (reference :500-552)"""
     model.eval()
     true, pred = [[] for _ in range(num_aspects)], [[] for _ in range(num_aspects)]
-    for batch in loader:
-        batch = tuple(t.to(device) if torch.is_tensor(t) else t for t in batch)
+    for batch in DevicePrefetcher(loader, device):
         t_img, roi_img, roi_coors, ids, tts, ams, added, labels, _ = batch
         vis, roi = features(t_img, roi_img)
         logits = model.forward_aspects(input_ids=ids, token_type_ids=tts, attention_mask=ams, added_attention_mask=added,

@@ -6,7 +6,12 @@ CE(ignore_index=-100) over [B,V,Ld], clip 1.0, AdamW (wd 1e-5 / 0, eps=--adam_ep
 schedule), same per-epoch checkpoint dict (:27-42,455-460).  Reference behaviours kept on purpose:
 `model.decoder.embedding` is re-created after construction (:189), which un-ties it from the
 encoder's word embeddings while `decoder.dense.weight` stays tied to them.
-Extra flags: --bf16, --synthetic_steps N (seeded synthetic batches, precomputed features).
+--fine_tune_cnn as in the reference (:203-207): the parameters of BOTH ResNet-152 extractors join the two AdamW groups
+(and the gradient arena / the data-parallel exchange), so the trunks really train; the extractors are checkpointed as
+`seed_{seed}_resimg_model_last.pth` / `..._resroi_model_last.pth` (:457-459) and restored on resume through the
+reference's `iaog_model` -> `resimg_model` / `resroi_model` path rewrite (:244-255).
+Extra flags: --bf16, --synthetic_steps N (seeded synthetic batches, precomputed features), --synthetic_pixels SIZE
+(those batches carry pixel crops and the HIP ResNet-152 trunks run inside the step).
 With real data the driver imports the user's `iaog_dataset.IAOGDataset` (host-side producer,
 SURVEY.md section 8(f) "next") and torchvision, as the reference does.
 """
@@ -27,6 +32,7 @@ from fcmf_framework import ops  # noqa: E402
 from fcmf_framework.dp import GradArena, GradReducer  # noqa: E402
 from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq  # noqa: E402
 from fcmf_framework.optimization import FusedAdamW, get_linear_schedule_with_warmup  # noqa: E402
+from device_prefetch import DevicePrefetcher  # noqa: E402
 
 
 def save_model(path, model, optimizer, scheduler, epoch, best_score=0.0):
@@ -69,6 +75,8 @@ def build_parser():
     p.add_argument('--feature_cache_dir', default=None, type=str,
                    help="precomputed ResNet-152 features of the training reviews (feature_cache.build); else pixels + the HIP trunk")
     p.add_argument('--resnet_checkpoint', default=None, type=str, help="torchvision resnet152 state dict for the HIP trunk")
+    p.add_argument('--synthetic_pixels', type=int, default=0,
+                   help="with --synthetic_steps: batches carry SIZE x SIZE pixel crops and the ResNet-152 trunks run inside the step")
     return p
 
 
@@ -106,8 +114,22 @@ def main(argv=None):
     model.decoder.embedding = torch.nn.Embedding(vocab, model.decoder.num_hiddens)       # reference :189
     model = model.to(device)
 
+    # the two ResNet-152 extractors (reference :191-194) whenever pixels enter the step: real data without a feature cache,
+    # or --synthetic_pixels
+    r_img = r_roi = None
+    if (args.synthetic_steps > 0 and args.synthetic_pixels > 0) or (args.synthetic_steps <= 0 and not args.feature_cache_dir):
+        from fcmf_framework.resnet import resnet152
+        from fcmf_framework.resnet_utils import myResNetImg, myResNetRoI
+        sd = torch.load(args.resnet_checkpoint, map_location='cpu', weights_only=True) if args.resnet_checkpoint else None
+        r_img = myResNetImg(resnet152(weights=sd).to(device), args.fine_tune_cnn, device).train()
+        r_roi = myResNetRoI(resnet152(weights=sd).to(device), args.fine_tune_cnn, device).train()
+
     no_decay = ['bias', 'LayerNorm.bias', 'LayerNorm.weight']
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    cnn_params = []
+    if args.fine_tune_cnn and r_img is not None:                     # reference :203-207 (names: 'resnet.conv1.weight', ...)
+        cnn_params = list(r_img.named_parameters()) + list(r_roi.named_parameters())
+        named += cnn_params
     groups = [{'params': [p for n, p in named if not any(nd in n for nd in no_decay)], 'weight_decay': 1e-5},
               {'params': [p for n, p in named if any(nd in n for nd in no_decay)], 'weight_decay': 0.0}]
     optimizer = FusedAdamW(groups, lr=args.learning_rate, eps=args.adam_epsilon)
@@ -125,6 +147,11 @@ def main(argv=None):
                 dec = torch.randint(3, vocab, (args.train_batch_size, args.synthetic_dec_len), generator=g)
                 lab = torch.roll(dec, -1, dims=1)
                 lab[:, -1] = -100                                                           # iaog_dataset.py:93-96
+                if args.synthetic_pixels:             # pixel crops in the IAOG dataset's float32 layout (iaog_dataset.py:148)
+                    S_, n_ = args.synthetic_pixels, args.train_batch_size * args.num_imgs
+                    b["visual_embeds_att"] = synth.synth_crops(n_, S_, seed=args.seed + i).view(args.train_batch_size, args.num_imgs, 3, S_, S_)
+                    b["roi_embeds_att"] = synth.synth_crops(n_ * args.num_rois, S_, seed=args.seed + i + 7919).view(
+                        args.train_batch_size, args.num_imgs, args.num_rois, 3, S_, S_)
                 yield (b["visual_embeds_att"], b["roi_embeds_att"], b["roi_coors"], b["input_ids"][:, 0],
                        b["token_type_ids"][:, 0], b["attention_mask"][:, 0], b["added_attention_mask"][:, 0], dec, lab)
         steps_per_epoch = args.synthetic_steps
@@ -156,26 +183,18 @@ def main(argv=None):
         if len(train_ds) == 0:
             raise SystemExit("train_dataset is empty: no 'sentiment_word#Aspect' labels in iaog_labels")
         sampler = DistributedSampler(train_ds) if world > 1 else RandomSampler(train_ds)      # shard once
-        loader = DataLoader(train_ds, sampler=sampler, batch_size=args.train_batch_size)
-        extract = None
-        if cache is None:
-            from fcmf_framework.resnet import resnet152
-            from fcmf_framework.resnet_utils import extract_features, myResNetImg, myResNetRoI
-            sd = torch.load(args.resnet_checkpoint, map_location='cpu', weights_only=True) if args.resnet_checkpoint else None
-            r_img = myResNetImg(resnet152(weights=sd).to(device), args.fine_tune_cnn, device).train()
-            r_roi = myResNetRoI(resnet152(weights=sd).to(device), args.fine_tune_cnn, device).train()
-            extract = lambda a, b: extract_features(r_img, r_roi, a.to(device), b.to(device))
+        loader = DataLoader(train_ds, sampler=sampler, batch_size=args.train_batch_size, pin_memory=True)
 
         def batches():
             for t_img, roi_img, coors, labels, dec, enc_ids, enc_type, enc_mask, added, _, _ in loader:
-                vis, roi = (t_img, roi_img) if extract is None else extract(t_img, roi_img)
-                yield (vis, roi, coors.float(), enc_ids, enc_type, enc_mask, added, dec, labels)
+                yield (t_img, roi_img, coors.float(), enc_ids, enc_type, enc_mask, added, dec, labels)
         steps_per_epoch = len(loader)
         make_loader = batches
 
     num_train_steps = int(steps_per_epoch / args.gradient_accumulation_steps * args.num_train_epochs)
     scheduler = get_linear_schedule_with_warmup(optimizer, int(num_train_steps * args.warmup_proportion), num_train_steps)
-    arena = GradArena.for_model(model)
+    # the trunks' gradients are produced LAST in backward (the extractors run first in the step): behind the model's in the arena
+    arena = GradArena.for_model(model, extra=[p for _, p in cnn_params])
     reducer = None
     if world > 1:
         reducer = GradReducer(arena)
@@ -184,16 +203,34 @@ def main(argv=None):
     if args.resume_from_checkpoint and os.path.isfile(args.resume_from_checkpoint):
         ck = torch.load(args.resume_from_checkpoint, map_location=device, weights_only=True)
         model.load_state_dict(ck['model_state_dict'])
+        for net, tag in ((r_img, "resimg_model"), (r_roi, "resroi_model")):           # reference :244-255
+            d, f = os.path.split(args.resume_from_checkpoint)
+            q = os.path.join(d, f.replace("iaog_model", tag))
+            if net is not None and os.path.exists(q):
+                if master:
+                    logger.info("    Loading ResNet: %s", q)
+                net.load_state_dict(torch.load(q, map_location=device, weights_only=True)['model_state_dict'])
         optimizer.load_state_dict(ck['optimizer_state_dict'])
         scheduler.load_state_dict(ck['scheduler_state_dict'])
         start_epoch = ck['epoch'] + 1
+        ops.shadows.clear()
+
+    def features(vis, roi):
+        """pixels -> ResNet-152 features (reference :305-317) unless the batch already holds features"""
+        if r_img is None:
+            return vis, roi
+        from fcmf_framework.resnet_utils import extract_features
+        return extract_features(r_img, r_roi, vis, roi.float())
 
     if args.do_train:
         for epoch in range(start_epoch, int(args.num_train_epochs)):
             model.train()
+            if r_img is not None:
+                r_img.train(); r_roi.train()
             arena.zero()
-            for step, batch in enumerate(make_loader()):
-                vis, roi, coors, enc_X, tt, am, added, dec_X, labels = (t.to(device) for t in batch)
+            for step, batch in enumerate(DevicePrefetcher(make_loader(), device)):
+                vis, roi, coors, enc_X, tt, am, added, dec_X, labels = batch
+                vis, roi = features(vis, roi)
                 # model(...) -> logits -> CrossEntropyLoss(ignore_index=-100) (reference :309-324) as one fused call
                 loss = model.forward_loss(enc_X, dec_X, labels, vis, roi, coors, tt, am, added, ignore_index=-100)
                 if args.gradient_accumulation_steps > 1:
@@ -214,6 +251,9 @@ def main(argv=None):
                 torch.distributed.barrier()
             if master:
                 save_model(f'{args.output_dir}/seed_{args.seed}_iaog_model_last.pth', model, optimizer, scheduler, epoch)
+                if r_img is not None:                                                   # reference :458-459
+                    save_model(f'{args.output_dir}/seed_{args.seed}_resimg_model_last.pth', r_img, optimizer, scheduler, epoch)
+                    save_model(f'{args.output_dir}/seed_{args.seed}_resroi_model_last.pth', r_roi, optimizer, scheduler, epoch)
     arena.deactivate()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -51,6 +51,136 @@ def test_finetune_driver_eval_path_and_resnet_in_the_loop(tmp_path, dev, caplog)
     assert "Dev macro-F1 per aspect" in log
     ck = torch.load(os.path.join(out, "seed_4_fcmf_model_last.pth"), map_location="cpu", weights_only=True)
     assert 0.0 <= ck["best_score"] <= 1.0 and ck["epoch"] == 0
+    # ---- the two ResNet-152 extractors are checkpointed beside the model under the reference's names (:557-563) ----------
+    for tag in ("resimg", "resroi"):
+        rk = torch.load(os.path.join(out, f"seed_4_{tag}_model_last.pth"), map_location="cpu", weights_only=True)
+        assert set(rk) >= {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"}
+        sd = rk["model_state_dict"]
+        assert "resnet.conv1.weight" in sd and "resnet.layer3.35.bn3.running_var" in sd and "resnet.bn1.num_batches_tracked" in sd
+        # train()-mode BatchNorm ran inside the step (reference :431): the running statistics have left their initial values
+        assert int(sd["resnet.bn1.num_batches_tracked"]) > 0 and not torch.equal(sd["resnet.bn1.running_mean"], torch.zeros(64))
+    # ---- test-set evaluation after training (reference :567-694): the two result files, in the reference's format ---------
+    res = open(os.path.join(out, "test_results_fcmf.txt")).read().splitlines()
+    assert res[0] == "***** Test results *****" and res[-1].startswith("Average F1: ")
+    aspects = ['Location', 'Food', 'Room', 'Facilities', 'Service', 'Public_area']
+    import re
+    for a, line in zip(aspects, res[1:7]):
+        assert re.fullmatch(rf"{a} - P: \d\.\d{{4}}, R: \d\.\d{{4}}, F1: \d\.\d{{4}}", line), line
+    fm = open(os.path.join(out, "test_predictions_formatted.txt"), encoding="utf-8").read()
+    assert fm.startswith("TEST DETAILED PREDICTIONS\nAverage Macro F1: ") and "Sentence 0: synthetic review" in fm
+    assert fm.count("{\n") == fm.count("}\n") == 2 and fm.count("   predict: ") == 2 * 6       # 1 test batch x 2 reviews x 6 aspects
+    assert all(v in ("None", "Negative", "Neutral", "Positive") for v in re.findall(r"predict: (\w+)", fm))
+    # ---- resume (round-2 advisor finding): the extractors come back from their own checkpoints, BatchNorm buffers included --
+    import run_multimodal_fcmf as drv2
+    seen = {}
+    orig = drv2.load_resnets
+
+    def spy(path, rimg, rroi, *a, **kw):
+        r = orig(path, rimg, rroi, *a, **kw)
+        seen["paths"] = r
+        seen["img_bn"] = rimg.state_dict()["resnet.bn1.running_mean"].detach().cpu().clone()
+        return r
+    drv2.load_resnets = spy
+    try:
+        drv2.main(["--output_dir", out, "--pretrained_hf_model", hf, "--do_train", "--num_imgs", "2", "--num_rois", "2",
+                   "--train_batch_size", "2", "--gradient_accumulation_steps", "1", "--synthetic_steps", "2",
+                   "--synthetic_pixels", "64", "--max_seq_length", "16", "--seed", "4", "--num_train_epochs", "1", "--bf16",
+                   "--resume_from_checkpoint", os.path.join(out, "seed_4_fcmf_model_last.pth")])
+    finally:
+        drv2.load_resnets = orig
+        ops.set_compute_dtype(torch.float32)
+    assert len(seen["paths"]) == 2 and seen["paths"][0].endswith("seed_4_resimg_model_last.pth")
+    want = torch.load(os.path.join(out, "seed_4_resimg_model_last.pth"), map_location="cpu", weights_only=True)
+    assert torch.equal(seen["img_bn"], want["model_state_dict"]["resnet.bn1.running_mean"])
+
+
+def test_pretraining_driver_fine_tune_cnn_moves_the_trunks(tmp_path, dev):
+    """--fine_tune_cnn (reference run_pretraining_fcmf.py:203-207): the parameters of both ResNet-152 extractors are in the
+    AdamW groups, so a step CHANGES the convolution weights; without the flag the same seed leaves them at their initial
+    values while the train()-mode BatchNorm statistics still drift.  Both runs write the extractors' checkpoints (:457-459);
+    a resume restores them through the `iaog_model` -> `resimg_model` rewrite (:244-255)."""
+    import run_pretraining_fcmf as drv
+    from fcmf_framework import ops
+    hf = make_hf_dir(synth.TINY_CFG)
+    common = ["--pretrained_hf_model", hf, "--do_train", "--num_imgs", "2", "--num_rois", "2", "--train_batch_size", "2",
+              "--synthetic_steps", "2", "--synthetic_dec_len", "5", "--synthetic_pixels", "64", "--num_train_epochs", "1",
+              "--seed", "6", "--bf16", "--learning_rate", "1e-3"]
+    try:
+        outs = {}
+        for name, extra in (("frozen", []), ("tuned", ["--fine_tune_cnn"])):
+            out = str(tmp_path / name)
+            drv.main(["--output_dir", out] + common + extra)
+            outs[name] = {t: torch.load(os.path.join(out, f"seed_6_{t}_model_last.pth"), map_location="cpu", weights_only=True)
+                          for t in ("resimg", "resroi", "iaog")}
+        for t in ("resimg", "resroi"):
+            f, g = outs["frozen"][t]["model_state_dict"], outs["tuned"][t]["model_state_dict"]
+            moved = [k for k in f if k.endswith("conv1.weight") or k.endswith("conv2.weight") or k.endswith("bn2.weight")]
+            assert len(moved) > 100
+            n_changed = sum(not torch.equal(f[k], g[k]) for k in moved)
+            assert n_changed == len(moved), (t, n_changed, len(moved))                   # every trunk weight received an update
+            assert all(torch.isfinite(g[k]).all() for k in g if g[k].is_floating_point())
+            assert int(f["resnet.bn1.num_batches_tracked"]) > 0                          # statistics drift either way
+        # the optimizer state of the tuned run covers the trunk parameters too
+        n_model = len(outs["frozen"]["iaog"]["optimizer_state_dict"]["state"])
+        assert len(outs["tuned"]["iaog"]["optimizer_state_dict"]["state"]) > n_model + 800      # 2 x ~465 trunk tensors (the unused fc layers receive no gradient)
+        # resume of the tuned run
+        out = str(tmp_path / "tuned")
+        drv.main(["--output_dir", out] + common + ["--fine_tune_cnn", "--num_train_epochs", "2", "--resume_from_checkpoint",
+                                                   os.path.join(out, "seed_6_iaog_model_last.pth")])
+        ck2 = torch.load(os.path.join(out, "seed_6_iaog_model_last.pth"), map_location="cpu", weights_only=True)
+        assert ck2["epoch"] == 1
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
+def test_device_prefetcher_hands_batches_to_hbm(tmp_path, dev):
+    """SURVEY section 8f.3, the device hand-off of the batch producer: the reference's tuple layout with float64 ROI crops
+    and boxes (vimacsa_dataset.py:188-202) and the bf16 feature cache arrive in HBM through pinned memory on a copy
+    stream -- values exact, order kept, float64 pixels -> float32 on the device (the reference's `.float()`), float64
+    boxes left alone, bf16 features bit-identical, strings passed through."""
+    from device_prefetch import DevicePrefetcher
+    from feature_cache import FeatureCache, FeatureCacheWriter
+    g = torch.Generator().manual_seed(0)
+    host = []
+    for i in range(5):
+        host.append((torch.randn(2, 2, 3, 16, 16, generator=g),                                   # images, float32
+                     torch.randn(2, 2, 3, 3, 16, 16, generator=g, dtype=torch.float64),           # ROI crops, float64
+                     torch.rand(2, 2, 3, 4, generator=g, dtype=torch.float64),                    # boxes, float64
+                     torch.randint(0, 100, (2, 6, 16), generator=g), torch.full((2, 6), i), [f"text {i}a", f"text {i}b"]))
+    pf = DevicePrefetcher(iter(host), dev)
+    assert pf.copy_stream != torch.cuda.current_stream(dev)
+    n = 0
+    for i, (img, roi, box, ids, lab, texts) in enumerate(pf):
+        assert img.is_cuda and roi.dtype == torch.float32 and box.dtype == torch.float64 and ids.dtype == torch.int64
+        assert torch.equal(img.cpu(), host[i][0]) and torch.equal(roi.cpu(), host[i][1].float())
+        assert torch.equal(box.cpu(), host[i][2]) and torch.equal(ids.cpu(), host[i][3]) and int(lab[0, 0]) == i
+        assert texts == host[i][5]
+        y = (img * 2).sum()                     # consume on the compute stream while the next copy is in flight
+        n += 1
+    assert n == 5 and pf.bytes_copied == sum(t.numel() * t.element_size() for b in host for t in b[:5])
+    # ---- bf16 feature cache -> HBM ------------------------------------------------------------------------------
+    path = str(tmp_path / "cache")
+    w = FeatureCacheWriter(path, 4, 2, 3)
+    vis = torch.randn(4, 2, 49, 2048, generator=g); roi = torch.randn(4, 2, 3, 2048, generator=g); co = torch.rand(4, 2, 3, 4, generator=g)
+    w.append(vis[:2], roi[:2], co[:2]); w.append(vis[2:], roi[2:], co[2:]); w.close()
+    cache = FeatureCache(path)
+
+    def batches():
+        for s in (0, 2):
+            items = [cache[s], cache[s + 1]]
+            yield tuple(torch.stack([it[k] for it in items]) for k in range(3))
+    got = list(DevicePrefetcher(batches(), dev))
+    assert len(got) == 2 and got[0][0].dtype == torch.bfloat16 and got[0][0].is_cuda
+    assert torch.equal(torch.cat([b[0] for b in got]).cpu(), vis.bfloat16())
+    assert torch.equal(torch.cat([b[1] for b in got]).cpu(), roi.bfloat16())
+    assert torch.equal(torch.cat([b[2] for b in got]).cpu(), co)
+    # an exception in the producer surfaces in the consumer
+
+    def bad():
+        yield (torch.zeros(2),)
+        raise ValueError("producer failed")
+    with pytest.raises(ValueError, match="producer failed"):
+        list(DevicePrefetcher(bad(), dev))
 
 
 def test_pretraining_driver_synthetic(tmp_path, dev):

@@ -54,13 +54,13 @@ def test_gemm_bf16_both_tile_kernels(dev, tile, ta, tb, M, N, K):
     B = _rand((K, N) if tb else (N, K), dev, torch.bfloat16, seed=2)
     bias = _rand((N,), dev, seed=3)
     C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    H.lib().fcmf_gemm_force_tile(tile)
+    H.set_gemm_tuning(tile=tile)
     try:
         ops.gemm(A, B, C, M, N, K, A.shape[1], B.shape[1], N, ta, tb, bias=bias)
         Cf = torch.full((M, N), 0.5, dtype=torch.float32, device=dev)
         ops.gemm(A, B, Cf, M, N, K, A.shape[1], B.shape[1], N, ta, tb, acc=True)
     finally:
-        H.lib().fcmf_gemm_force_tile(0)
+        H.set_gemm_tuning(tile=0)
     Af = A.float().cpu().t() if ta else A.float().cpu()
     Bf = B.float().cpu() if tb else B.float().cpu().t()
     assert rel_err(C, Af @ Bf + bias.cpu()) < 2e-2
@@ -78,8 +78,8 @@ def test_gemm_k64_and_k32_kernels_agree_bitwise(dev, M, N, K, epi):
     u = _rand((M, N), dev, torch.bfloat16, 1.5, seed=5)
     outs = []
     for kb in (32, 64):
-        H.lib().fcmf_gemm_force_kb(kb)
-        H.lib().fcmf_gemm_force_tile(256)          # the persistent kernels also for the small ragged case
+        H.set_gemm_tuning(kb=kb)
+        H.set_gemm_tuning(tile=256)          # the persistent kernels also for the small ragged case
         try:
             C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
             aux = torch.empty_like(C)
@@ -91,10 +91,10 @@ def test_gemm_k64_and_k32_kernels_agree_bitwise(dev, M, N, K, epi):
                 ops.gemm(A, B, C, M, N, K, K, K, N, False, False, aux=u, epi=H.EPI_DGELU)
             else:
                 ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, aux=u, epi=H.EPI_ADD)
-            outs.append((C.clone(), aux.clone() if epi == "gelu" else None, H.lib().fcmf_gemm_last_kernel().decode()))
+            outs.append((C.clone(), aux.clone() if epi == "gelu" else None, H.last_gemm_kernel()))
         finally:
-            H.lib().fcmf_gemm_force_kb(64)
-            H.lib().fcmf_gemm_force_tile(0)
+            H.set_gemm_tuning(kb=64)
+            H.set_gemm_tuning(tile=0)
     assert "k64" not in outs[0][2] and "k64" in outs[1][2], (outs[0][2], outs[1][2])
     assert torch.equal(outs[0][0], outs[1][0])
     if epi == "gelu":
@@ -115,7 +115,7 @@ def test_gemm_tile256_epilogues(dev, tile, M, N, K, nk_note):
     bias = _rand((N,), dev, seed=3)
     Af, Bf = A.float().cpu(), B.float().cpu()
     pre = Af @ Bf.t() + bias.cpu()
-    H.lib().fcmf_gemm_force_tile(tile)
+    H.set_gemm_tuning(tile=tile)
     try:
         C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         aux = torch.empty_like(C)
@@ -137,7 +137,7 @@ def test_gemm_tile256_epilogues(dev, tile, M, N, K, nk_note):
         ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, aux=u, epi=H.EPI_ADD)
         assert rel_err(C, pre + uf) < 2e-2
     finally:
-        H.lib().fcmf_gemm_force_tile(0)
+        H.set_gemm_tuning(tile=0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -187,20 +187,23 @@ def test_gemm_weight_grad_splitk_workspace_and_atomics(dev, workspace):
     N, K, Mtok = 768, 768, 8200
     dY, X = _rand((Mtok, N), dev, torch.bfloat16, seed=1), _rand((Mtok, K), dev, torch.bfloat16, seed=2)
     dW = torch.ones((N, K), dtype=torch.float32, device=dev)
-    st = H.stream()
     try:
         if not workspace:
-            ops._ensure_splitk_workspace(dev)
-            H.check(H.lib().fcmf_gemm_set_workspace(None, 0, st), "unregister")
-            H.check(H.lib().fcmf_gemm(H.ptr(dY), H.ptr(X), H.ptr(dW), None, None, None, N, K, Mtok, N, K, K, 1, 1,
-                                      H.dt(dY), H.dt(dW), H.EPI_NONE, 1, st), "fcmf_gemm")
+            H.drop_gemm_workspace()        # a context without a workspace: k-split partials are added with float atomics
+            H.check(H.lib().fcmf_gemm(H.gemm_ctx(), H.ptr(dY), H.ptr(X), H.ptr(dW), None, None, None, N, K, Mtok, N, K, K, 1, 1,
+                                      H.dt(dY), H.dt(dW), H.EPI_NONE, 1, H.stream()), "fcmf_gemm")
+            # ... and a NULL context (defaults) is legal too
+            dW0 = torch.ones((N, K), dtype=torch.float32, device=dev)
+            H.check(H.lib().fcmf_gemm(None, H.ptr(dY), H.ptr(X), H.ptr(dW0), None, None, None, N, K, Mtok, N, K, K, 1, 1,
+                                      H.dt(dY), H.dt(dW0), H.EPI_NONE, 1, H.stream()), "fcmf_gemm")
+            assert rel_err(dW0, dW) < 1e-5
         else:
             ops.gemm(dY, X, dW, N, K, Mtok, N, K, K, 1, 1, acc=True)
-        assert H.lib().fcmf_gemm_last_kernel().decode() == "gemm_bf16_tile256_kernel<1,1,f32,NONE>"
+        assert H.last_gemm_kernel() == "gemm_bf16_tile256_kernel<1,1,f32,NONE>"
         ref = dY.float().cpu().t() @ X.float().cpu() + 1.0
         assert rel_err(dW, ref) < 2e-3
     finally:
-        ops._splitk_ws.clear()          # the next accumulate GEMM registers a fresh workspace
+        pass                               # (the next accumulate GEMM re-registers a workspace with its context)
 
 
 def test_gemm_strided_rows(dev):
@@ -814,8 +817,9 @@ def test_attention_mfma_padded_sequences_skip_is_exact(dev, T, p):
 def test_attention_mfma_fully_masked_sequence_is_uniform(dev, T):
     """a sequence whose EVERY key carries the hard (finfo.min) mask: torch / the reference absorb the scores into finfo.min
     and softmax is uniform over all T keys (HF eager attention, modeling_roberta.py:158-183).  The MFMA kernels must not
-    shorten such a row to its first key fragment (round-2 advisor finding): out = mean of V, dv = dout / T per key, dq = dk = 0,
-    in both the MFMA and the VALU kernel, next to a normal and a half-padded sequence in the same launch."""
+    shorten such a row to its first key fragment (round-2 advisor finding): out = mean of V, dv = dout / T per key,
+    in both the MFMA and the VALU kernel, next to a normal and a half-padded sequence in the same launch.
+    The backward recomputes probabilities from the saved logsumexp, which for such a row is finfo.min itself (log T is absorbed)."""
     from fcmf_framework import ops
     heads, d = 2, 64
     HD = heads * d
@@ -841,10 +845,9 @@ def test_attention_mfma_fully_masked_sequence_is_uniform(dev, T):
             ops.USE_MFMA_ATTENTION = True
         assert rel_err(out, ref) < 2e-2, use
         assert rel_err(v.grad, vr.grad) < 3e-2, use
-        assert rel_err(q.grad[[0, 2]], qr.grad[[0, 2]]) < 3e-2 and rel_err(k.grad[[0, 2]], kr.grad[[0, 2]]) < 3e-2, use
-        # the fully masked sequence: uniform probabilities -> no dependence on q / k
-        assert q.grad[1].float().abs().max().item() < 1e-2 * qr.grad[0].abs().max().item(), use
-        assert k.grad[1].float().abs().max().item() < 1e-2 * kr.grad[0].abs().max().item(), use
+        # (autograd semantics: the gradient flows through `scores + mask` with derivative 1 although finfo.min absorbs the
+        #  scores in the forward, so dq / dk of the fully masked sequence are those of uniform probabilities, not zero)
+        assert rel_err(q.grad, qr.grad) < 3e-2 and rel_err(k.grad, kr.grad) < 3e-2, use
 
 
 @pytest.mark.parametrize("Tq,Tk", [(128, 128), (77, 128), (128, 50), (33, 17), (256, 256), (200, 256), (256, 150), (130, 129)])

@@ -24,7 +24,10 @@ static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFF
 int main(int argc, char** argv) {
   int reps = argc > 1 ? atoi(argv[1]) : 20;
   int tile = argc > 2 ? atoi(argv[2]) : 0;
-  fcmf_gemm_force_tile(tile);
+  fcmf_gemm_ctx* ctx = nullptr;
+  fcmf_gemm_ctx_create(&ctx);
+  fcmf_gemm_ctx_tune(ctx, tile, getenv("FCMF_GEMM_KB") && atoi(getenv("FCMF_GEMM_KB")) == 32 ? 32 : -1,
+                     getenv("FCMF_GEMM_CUS") ? atoi(getenv("FCMF_GEMM_CUS")) : -1, -1);
   printf("---- forced tile: %d (0 = heuristic)\n", tile);
   const int T = 49152;
   std::vector<Shape> shapes = {
@@ -84,7 +87,7 @@ int main(int argc, char** argv) {
   if (!getenv("FCMF_BENCH_NO_WS")) {   // split-K workspace (plain stores + reduce pass instead of float atomics)
     void* ws; const size_t wsb = 96u << 20;
     hipMalloc(&ws, wsb);
-    fcmf_gemm_set_workspace(ws, (int64_t)wsb, nullptr);
+    fcmf_gemm_ctx_set_workspace(ctx, ws, (int64_t)wsb);
   }
   const int hog = getenv("FCMF_BENCH_HOG") ? atoi(getenv("FCMF_BENCH_HOG")) : 0;   // CUs taken away by a co-running kernel
   hipStream_t hs; hipStreamCreate(&hs);
@@ -95,7 +98,7 @@ int main(int argc, char** argv) {
     if (only && strncmp(sh.name, only, strlen(only)) != 0) continue;
     int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.N : sh.K, ldc = sh.N;
     auto run = [&]() {
-      return fcmf_gemm(A, B, C, sh.acc ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU || sh.epi == FCMF_EPI_ADD) ? AUX : nullptr, nullptr,
+      return fcmf_gemm(ctx, A, B, C, sh.acc ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU || sh.epi == FCMF_EPI_ADD) ? AUX : nullptr, nullptr,
                        sh.M, sh.N, sh.K, lda, ldb, ldc, sh.ta, sh.tb, FCMF_BF16, sh.out_f32 ? FCMF_F32 : FCMF_BF16, sh.epi, sh.acc, nullptr);
     };
     int rc = run(); rc |= run();

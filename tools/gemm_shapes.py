@@ -14,7 +14,7 @@ seen = {}
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=0, acc=False, colsum=None):
     orig(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=bias, aux=aux, epi=epi, acc=acc, colsum=colsum)
-    key = (H.lib().fcmf_gemm_last_kernel().decode(), M, N, K, int(ta), int(tb), int(acc))
+    key = (H.last_gemm_kernel(), M, N, K, int(ta), int(tb), int(acc))
     seen[key] = seen.get(key, 0) + 1
 
 

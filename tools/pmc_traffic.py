@@ -6,7 +6,7 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for wide
 coalesced reads, so it is doubled (the guide's correction) -- WRITE_SIZE is exact for 16-byte stores and float atomics.
-Kernel names are normalised to the names `fcmf_gemm_last_kernel()` reports so that bench.py can look them up."""
+Kernel names are normalised to the names `fcmf_gemm_ctx_last_kernel()` reports so that bench.py can look them up."""
 import csv
 import hashlib
 import json
