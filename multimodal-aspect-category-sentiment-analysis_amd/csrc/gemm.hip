@@ -21,6 +21,7 @@ struct GemmParams {
   int tiles, total_items;      // persistent big kernel: output tiles, tiles x k-splits
   float* ws;                   // split-K partial tiles [ksplit][M][N] (plain stores + a reduce pass) or null (float atomics)
   int nt_out;                  // bf16 epilogue: nontemporal stores (streamed outputs must not evict the operands from L2)
+  const float* sa; const float* sb;   // fp8 kernels: per-row dequantisation scales of A [M] and of B [N]
 };
 
 // bf16-output epilogues use odd polynomials instead of erf/exp (no transcendental issue slots, no
@@ -363,9 +364,19 @@ __device__ __forceinline__ int swz_row64(int r) { return (r >> 1) & 7; }
 //  KB = 64: K-contiguous tile = 8 rows x 128 B per piece (every 128-B line is fetched by ONE wave instruction:
 //           with 64-B row pieces the CU's L2->L1 path moves each line twice, measured 1.5x slower);
 //           transposed tile as for KB = 32 with 64 k-rows.
-template <bool TR, int KB>
+//  FP8 (KB = 64 geometry, 128 e4m3 per 128-B row): lane group g of v_mfma_scale_f32_16x16x128_f8f6f4 consumes 32 CONSECUTIVE
+//           k of a row = the two 16-B chunks 2g, 2g+1; they are stored where the bf16 kernel's fragment reads look
+//           (physical chunk (g ^ swizzle) and the same + 4: conflict-free ds_read_b128 pairs), i.e. logical chunk
+//           c = 2g + h lives at physical chunk (g | h << 2) ^ swizzle.
+template <bool TR, int KB, bool FP8 = false>
 __device__ __forceinline__ unsigned dma_voffset_t(int piece, int lane, int64_t ld, int x0, int xdim) {
   const int q = piece * 64 + lane;             // 16-B slot inside the operand tile
+  if constexpr (FP8) {
+    static_assert(!TR && KB == 64, "fp8 tiles: K-contiguous operands, 128-byte rows");
+    const int row = q >> 3, x = (q & 7) ^ swz_row64(row), c = ((x & 3) << 1) | (x >> 2);
+    if (x0 + row >= xdim) return 0x80000000u;
+    return (unsigned)((int64_t)(x0 + row) * ld + c * 16);
+  }
   if (!TR && KB == 32) {
     const int row = q >> 2, c = (q & 3) ^ swz_row(row);
     if (x0 + row >= xdim) return 0x80000000u;
@@ -399,10 +410,18 @@ __device__ __forceinline__ void store8f(float* q, const f32x2 (&v)[4]) {
 // rounds on 256 CUs, the last one a quarter full) but 768 tiles of 192 rows = exactly 3 rounds of 3/4 the work.
 // KB = depth of a k-tile: 32 (4-stage ring, three k-tiles in flight) or 64 (2-stage ring, ONE k-tile in flight, half
 // the barriers; K-contiguous operands then arrive as whole 128-B lines -- see dma_voffset_t).
-template <bool A_TR, bool B_TR, typename TC, int EPI, int MI, int KB>
+// FP8: e4m3 operands (K-contiguous, KB = 64 geometry = 128 elements per 128-byte row), v_mfma_scale_f32_16x16x128_f8f6f4 with
+// unit block scales (2x the bf16 MFMA rate per clock), per-row dequantisation scales applied to the f32 accumulators in the
+// epilogue (acc[i][j] * sa[i] * sb[j]).  Ring, DMA pieces, swizzled LDS image and fragment READ addresses are those of the
+// bf16 64-deep kernel; a k-tile is consumed in two M-halves (B fragments + A fragments 0-3, then A fragments 4-7) instead of
+// two K-halves, so the fragment registers stay at 64.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <bool A_TR, bool B_TR, typename TC, int EPI, int MI, int KB, bool FP8 = false>
 __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   static_assert(MI == 8 || (MI == 6 && !A_TR && sizeof(TC) == 2), "192-row tiles: row-major A, bf16 output");
   static_assert(KB == 32 || KB == 64, "k-tile depth");
+  static_assert(!FP8 || (KB == 64 && !A_TR && !B_TR && sizeof(TC) == 2), "fp8: K-contiguous operands, bf16 output");
+  constexpr int KE = FP8 ? 2 * KB : KB;       // contraction elements per k-tile
   constexpr int NW = 8;
   constexpr int TM = 32 * MI;                  // block tile rows
   constexpr int WM = 16 * MI;                  // rows per wave
@@ -430,7 +449,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     int q = nblk >> 3, r = nblk & 7, xcd = slot & 7, local = slot >> 3;
     slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int nk_total = (p.K + KB - 1) / KB;
+  const int nk_total = (p.K + KE - 1) / KE;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
   constexpr bool ASM_DMA = A_TR || B_TR;    // (see dma16_asm: transposed fragment reads must not see a compiler-visible LDS-DMA)
@@ -495,9 +514,9 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   auto sources = [&](const Item& w) -> Src {
     Src r;
 #pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR, KB>(a_piece0 + j, lane, p.lda, w.i0, p.M);
+    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR, KB, FP8>(a_piece0 + j, lane, p.lda, w.i0, p.M);
 #pragma unroll
-    for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR, KB>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
+    for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR, KB, FP8>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
     return r;
   };
   // DMA of k-tile t of item w: A tile to sa and / or B tile to sb (nullptr = skip)
@@ -591,6 +610,33 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 #pragma unroll
     for (int f = 0; f < MI; ++f) fa[f] = frag_a(sa, f, h);
   };
+  // fp8: `h` counts the M-halves of the k-tile (h = 0: the B fragments and A fragments 0-3, h = 1: A fragments 4..MI-1)
+  [[maybe_unused]] i32x8 qa[FP8 ? 4 : 1], qb[FP8 ? 4 : 1];
+  auto frag32 = [&](const char* st, int lane_off, int f) -> i32x8 {   // 32 consecutive k of row (lane & 15) of fragment f
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(st + lane_off + f * (32 * KB));
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(st + (lane_off ^ 64) + f * (32 * KB));
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  auto load_frags8 = [&](auto half) {
+    constexpr int h = decltype(half)::value;
+    const char* sa = slot_at(0);
+    if constexpr (h == 0) {
+      const char* sb = slot_at(1);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) qb[f] = frag32(sb, b_lane, f);
+    }
+#pragma unroll
+    for (int f = 0; f < (h == 0 ? 4 : MI - 4); ++f) qa[f] = frag32(sa, a_lane, 4 * h + f);
+  };
+  auto mma8 = [&](auto half) {
+    constexpr int h = decltype(half)::value;
+#pragma unroll
+    for (int fi = 0; fi < (h == 0 ? 4 : MI - 4); ++fi)
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj)
+        // e4m3 x e4m3 (cbsz = blgp = 0), E8M0 block scales 127 = 2^0 for both operands
+        acc[fj][4 * h + fi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qb[fj], qa[fi], acc[fj][4 * h + fi], 0, 0, 0, 127, 0, 127);
+  };
   auto mma = [&]() {
 #pragma unroll
     for (int fi = 0; fi < MI; ++fi)
@@ -643,10 +689,15 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       if constexpr (EARLY_AUX) {
         if (t == nkt - 1) { load_aux(0); load_aux(1); }
       }
+      if constexpr (FP8) {
+        load_frags8(IntTag<0>{}); mma8(IntTag<0>{});
+        load_frags8(IntTag<1>{}); mma8(IntTag<1>{});
+      } else {
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        load_frags(t, h);
-        mma();
+        for (int h = 0; h < NH; ++h) {
+          load_frags(t, h);
+          mma();
+        }
       }
       if constexpr (RING5) { base += 2; base = base >= 5 ? base - 5 : base; }
     }
@@ -655,17 +706,24 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       wait_landed(t, IntTag<(MI == 8 ? 4 : 3)>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads of tile t-1 have left LDS
       __builtin_amdgcn_s_barrier();
-      if (t > 0) mma();                                     // last half of tile t-1
-      issue_after_barrier(t);
+      if constexpr (FP8) {
+        if (t > 0) mma8(IntTag<1>{});                       // second M-half of tile t-1
+        issue_after_barrier(t);
+        load_frags8(IntTag<0>{}); mma8(IntTag<0>{});
+        load_frags8(IntTag<1>{});
+      } else {
+        if (t > 0) mma();                                   // last half of tile t-1
+        issue_after_barrier(t);
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        load_frags(t, h);
-        if (h + 1 < NH) mma();
+        for (int h = 0; h < NH; ++h) {
+          load_frags(t, h);
+          if (h + 1 < NH) mma();
+        }
       }
       if constexpr (RING5) { base += 2; base = base >= 5 ? base - 5 : base; }
     }
     if constexpr (EARLY_AUX) { load_aux(0); load_aux(1); }
-    mma();                                                  // last half of the last tile (nkt >= 1 always)
+    if constexpr (FP8) mma8(IntTag<1>{}); else mma();       // last half of the last tile (nkt >= 1 always)
   }
   if constexpr (HAS_AUX) {
 #pragma unroll
@@ -715,6 +773,22 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
           if (1 < wnx.nkt) issue(wnx, snx, 1, nkt + 1);
           if (2 < wnx.nkt) issue(wnx, snx, 2, nkt + 2);
         }
+      }
+    }
+    if constexpr (FP8) {
+      // acc[i][j] of quantised operands -> x sa[i] x sb[j] (row scales of A and of B), before the bias
+      f32x4 sbq[4];
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) {
+        const int gj = j0 + wn * 64 + eg * 4 + fj * 16;
+        sbq[fj] = gj < p.N ? *reinterpret_cast<const f32x4*>(p.sb + gj) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int fi = 0; fi < MI; ++fi) {
+        const int gi = i0 + wm * WM + fi * 16 + er;
+        const float sai = gi < p.M ? p.sa[gi] : 0.f;
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) acc[fj][fi] = acc[fj][fi] * (sbq[fj] * sai);
       }
     }
     if (p.bias) {
@@ -1091,6 +1165,29 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tile192k64_kernel(GemmParams
   gemm_bf16_tile256_body<false, false, bf16_t, EPI, 6, 64>(p);
 }
 
+// e4m3 operands (see the body): K % 128 == 0, bf16 output
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_fp8_tile256_kernel(GemmParams p) {
+  gemm_bf16_tile256_body<false, false, bf16_t, EPI, 8, 64, true>(p);
+}
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_fp8_tile192_kernel(GemmParams p) {
+  gemm_bf16_tile256_body<false, false, bf16_t, EPI, 6, 64, true>(p);
+}
+template <int EPI>
+static void launch_fp8_tile(const GemmParams& p, dim3 grid, hipStream_t st, int tm) {
+  const size_t smem = (size_t)RING_BYTES + 8 * 4096;
+  if (tm == 192) {
+    auto k = gemm_fp8_tile192_kernel<EPI>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+  } else {
+    auto k = gemm_fp8_tile256_kernel<EPI>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+  }
+}
+
 template <bool A_TR, bool B_TR, typename TC, int EPI>
 static void launch_bf16_tile_typed(const GemmParams& p, dim3 grid, hipStream_t st, int tm, int kb) {
   const size_t smem = (size_t)RING_BYTES + 8 * 4096;   // ring + per-wave transposition slices = 160 KiB
@@ -1221,7 +1318,7 @@ extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void*
                     (trans_a || K % BK == 0) && (trans_b || K % BK == 0) &&
                     (((int64_t)(trans_a ? K : M) * lda) < (1ll << 30)) && (((int64_t)(trans_b ? K : N) * ldb) < (1ll << 30));
   if (fast) {
-    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr};
+    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, nullptr, nullptr};
     // bytes addressable through each operand: (rows - 1) * ld + contiguous extent
     p.a_bytes = (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
     p.b_bytes = (unsigned)((((int64_t)(trans_b ? K : N) - 1) * ldb + (trans_b ? N : K)) * 2);
@@ -1326,6 +1423,98 @@ extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void*
     hipLaunchKernelGGL((gemm_generic_kernel<bf16_t, float>), grid, dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL((gemm_generic_kernel<float, bf16_t>), grid, dim3(256), 0, st, g);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+// ---- e4m3 GEMM ---------------------------------------------------------------------------------------------------------
+extern "C" int fcmf_gemm_fp8(fcmf_gemm_ctx* ctx, const void* A, const float* sa, const void* B, const float* sb, void* C,
+                             const float* bias, void* aux, float* colsum, int M, int N, int K, int64_t lda, int64_t ldb,
+                             int64_t ldc, int epilogue, void* stream) {
+  if (!A || !B || !C || !sa || !sb || M < 0 || N < 0 || K <= 0) return FCMF_ERR_ARG;
+  if (M == 0 || N == 0) return FCMF_OK;
+  if ((epilogue == FCMF_EPI_DGELU || epilogue == FCMF_EPI_ADD) && !aux) return FCMF_ERR_ARG;
+  if (epilogue == FCMF_EPI_TANH || epilogue == FCMF_EPI_DTANH) return FCMF_ERR_UNSUPPORTED;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const int64_t c_extent = (((int64_t)M - 1) * ldc + N) * 2;
+  // 128-byte k-tiles of whole cache lines; 16-byte DMA chunks; the persistent kernels' 8-column row pieces
+  if (K % 128 || lda % 16 || ldb % 16 || N % 8 || ldc % 8 || !al16(A) || !al16(B) || !al16(C) || (aux && !al16(aux)) ||
+      (bias && !al16(bias)) || !al16(sb) || c_extent >= (1ll << 31) || (int64_t)M * lda >= (1ll << 31) ||
+      (int64_t)N * ldb >= (1ll << 31) || M < 256 || N < 256)
+    return FCMF_ERR_UNSUPPORTED;
+  const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
+  GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, 0, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, sa, sb};
+  p.a_bytes = (unsigned)(((int64_t)M - 1) * lda + K);
+  p.b_bytes = (unsigned)(((int64_t)N - 1) * ldb + K);
+  p.c_bytes = (unsigned)c_extent;
+  const int slots = cfg.num_cus, nk = K / 128;
+  int tm = 256;
+  auto cost = [&](int rows) {
+    const int64_t t = (int64_t)((M + rows - 1) / rows) * ((N + GB - 1) / GB);
+    return (double)((t + slots - 1) / slots) * (2.0 * nk * (rows / 256.0) + 8.0);
+  };
+  if (cfg.force_tile == 192 || (cfg.force_tile == 0 && cost(192) < 0.97 * cost(256))) tm = 192;
+  p.tiles = ((M + tm - 1) / tm) * ((N + GB - 1) / GB);
+  p.ktiles_per_split = nk;
+  p.ksplit = 1;
+  p.total_items = p.tiles;
+  p.nt_out = (int64_t)M * N * 2 >= cfg.nt_min_bytes;
+  dim3 grid(p.total_items < slots ? p.total_items : slots);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ctx) {
+    static const char* const epi_names[] = {"NONE", "GELU", "TANH", "DGELU", "DTANH", "ADD"};
+    snprintf(ctx->last_kernel, sizeof ctx->last_kernel, "gemm_fp8_tile%d_kernel<%s>", tm, epi_names[epilogue]);
+  }
+  switch (epilogue) {
+    case FCMF_EPI_NONE: launch_fp8_tile<FCMF_EPI_NONE>(p, grid, st, tm); break;
+    case FCMF_EPI_GELU: launch_fp8_tile<FCMF_EPI_GELU>(p, grid, st, tm); break;
+    case FCMF_EPI_DGELU: launch_fp8_tile<FCMF_EPI_DGELU>(p, grid, st, tm); break;
+    default: launch_fp8_tile<FCMF_EPI_ADD>(p, grid, st, tm); break;
+  }
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+// x [rows, K] (bf16 / f32, row stride ldx) -> q [rows, K] e4m3 (row stride ldq bytes) with ONE scale per row:
+// scale[r] = amax_r / 448 (1 for an all-zero row), q = round_to_nearest_even(x / scale[r]).  One wave per row, 8 elements per
+// lane and trip; the row is read twice (the second pass hits L2).
+template <typename T>
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const T* __restrict__ x, int64_t ldx, unsigned char* __restrict__ q,
+                                                             int64_t ldq, float* __restrict__ scale, int rows, int K) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * ldx;
+  float amax = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const float4 a = Vec4<T>::load(xr + k), b = Vec4<T>::load(xr + k + 4);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f, inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  unsigned char* qr = q + (int64_t)row * ldq;
+  for (int k = lane * 8; k < K; k += 512) {
+    const float4 a = Vec4<T>::load(xr + k), b = Vec4<T>::load(xr + k + 4);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(a.x * inv, a.y * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(a.z * inv, a.w * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(b.x * inv, b.y * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(b.z * inv, b.w * inv, hi, true);
+    *reinterpret_cast<int2*>(qr + k) = make_int2(lo, hi);
+  }
+}
+
+extern "C" int fcmf_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, int dtype,
+                                   void* stream) {
+  if (!x || !q || !scale || rows < 0 || K <= 0) return FCMF_ERR_ARG;
+  if (K % 8 || ldx % 8 || ldq % 8 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(q) & 7)) return FCMF_ERR_UNSUPPORTED;
+  if (rows == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((rows + 3) / 4);
+  if (dtype == FCMF_BF16) hipLaunchKernelGGL((quant_fp8_rows_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, (unsigned char*)q, ldq, scale, rows, K);
+  else if (dtype == FCMF_F32) hipLaunchKernelGGL((quant_fp8_rows_kernel<float>), grid, dim3(256), 0, st, (const float*)x, ldx, (unsigned char*)q, ldq, scale, rows, K);
+  else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
