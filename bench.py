@@ -16,7 +16,7 @@ Other workloads print their OWN line (never mixed into the headline metric):
   --workload iaog    IAOG seq2seq pre-training step (BASELINE configs[3] geometry per GPU: B=64, seq 128, Ld=12,
                      vocab 64001, 4 ROIs as run_pretraining_fcmf.py defaults), fused vocabulary projection + loss
   --workload resnet  the ResNet-152 feature extractor of the step: crops/s of the batched trunk
-  --workload fcmf-large  BASELINE configs[4] geometry (XLM-R-large, seq 256, 100 ROIs) in bf16 (its fp8 path is not built)
+  --workload fcmf-large  BASELINE configs[4] geometry (XLM-R-large, seq 256, 100 ROIs); --dtype fp8 = its e4m3 MFMA path, bf16 for comparison
 
 One JSON line on stdout (rank 0).  `roofline` describes the dominant kernel (the bf16 MFMA GEMM family):
 achieved = executed GEMM FLOPs / summed launch durations measured with HIP events on the launch stream during the
@@ -41,6 +41,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA peak (block-scaled form, same table)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table); ~6.3 TB/s is what a streaming copy achieves
 
 BASE_CFG = dict(vocab_size=64001, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
@@ -143,7 +144,7 @@ def gemm_roofline(trace):
     for name, flops, ms in trace:
         e = per.setdefault(name, [0, 0.0, 0.0])
         e[0] += 1; e[1] += flops; e[2] += ms
-    mf = {k: v for k, v in per.items() if k.startswith("gemm_bf16_")}   # the bf16 MFMA kernels (tile256 / tile192 / 128x128)
+    mf = {k: v for k, v in per.items() if k.startswith(("gemm_bf16_", "gemm_fp8_"))}   # the MFMA kernels (tile256 / tile192 / 128x128; e4m3)
     if not mf:
         return None
     dom = max(mf, key=lambda k: mf[k][2])
@@ -151,8 +152,9 @@ def gemm_roofline(trace):
     tot_fl, tot_ms = sum(v[1] for v in mf.values()), sum(v[2] for v in mf.values())
     ach = fl / (ms * 1e-3) / 1e12
     traffic, src = committed_traffic(dom)
-    return dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_source=src, launches=n,
+    peak = PEAK_FP8_TFLOPS if dom.startswith("gemm_fp8_") else PEAK_BF16_TFLOPS
+    return dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
+                frac=round(ach / peak, 4), traffic=traffic, traffic_source=src, launches=n,
                 avg_launch_ms=round(ms / n, 4), flops_per_launch=fl / n,
                 all_bf16_gemms=dict(launches=sum(v[0] for v in mf.values()), achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
                                     ms_per_step=round(tot_ms, 3)),
@@ -208,7 +210,8 @@ def run_fcmf(args, rank, world, dev, large=False):
     model = FCMF(hf, num_labels=4, num_imgs=NI, num_roi=NR).to(dev)
     model.train(not args.no_dropout)
     ops.manual_seed(42 + rank)
-    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    ops.set_compute_dtype(torch.float32 if args.dtype == "fp32" else torch.bfloat16)
+    ops.set_fp8(args.dtype == "fp8")     # forward + dX GEMMs on e4m3 operands (BASELINE configs[4]); everything else as in bf16
     opt = FusedAdamW(param_groups(model), lr=7e-4)
     sched = get_linear_schedule_with_warmup(opt, int(0.1 * 1000), 1000)
     red = arena = None
@@ -263,13 +266,13 @@ def run_fcmf(args, rank, world, dev, large=False):
     ms_step_pf = (time.perf_counter() - t0) / n_pf * 1e3
     ms_step = dt / args.steps * 1e3
     out = {
-        "metric": "train samples/sec (fwd+bwd+step) FCMF-large seq256x100ROI (bf16; the fp8 path of BASELINE configs[4] is not built)"
+        "metric": f"train samples/sec (fwd+bwd+step) FCMF-large seq256x100ROI ({args.dtype}; BASELINE configs[4])"
         if large else "train samples/sec (fwd+bwd+step) FCMF seq128x36ROI",
         "value": round(world * B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (seeded batch, random-init weights)",
         "config": {"workload": (f"FCMF-large (XLM-R-large geometry H1024 L24 heads16 I4096 vocab 250002) fine-tune step, BASELINE configs[4] "
-                                f"geometry in bf16: batch {B} reviews x 6 aspects per GPU, seq 256, 7 images x (49 patches + 100 ROIs), "
+                                f"geometry in {args.dtype}: batch {B} reviews x 6 aspects per GPU, seq 256, 7 images x (49 patches + 100 ROIs), "
                                 "precomputed features, dropout " if large else
                                 "FCMF-base fine-tune step, BASELINE configs[1]: batch 64 reviews x 6 aspects per GPU, "
                                 "seq 128, 7 images x (49 patches + 36 ROIs), precomputed ResNet-152 features, dropout ")
@@ -395,7 +398,8 @@ def main():
     ap.add_argument("--workload", default="fcmf", choices=["fcmf", "fcmf-large", "iaog", "resnet"])
     ap.add_argument("--batch", type=int, default=None, help="reviews per GPU (default 64; fcmf-large: 16)")
     ap.add_argument("--dec_len", type=int, default=12, help="IAOG decoder length")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8: e4m3 forward / dX GEMMs (v_mfma_scale_f32_16x16x128_f8f6f4) with bf16 weight-gradient GEMMs: --workload fcmf-large")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-arena", dest="no_arena", action="store_true",

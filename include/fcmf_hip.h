@@ -88,6 +88,24 @@ int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, const f
               int trans_a, int trans_b, int in_dtype, int out_dtype,
               int epilogue, int accumulate, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * FP8 (OCP e4m3fn) path of BASELINE configs[4] (FCMF-large): forward and dX GEMMs on the block-scaled matrix instruction
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 MFMA rate), float32 accumulation; weight gradients stay bf16.
+ * The only "large" hook of the reference is the constant block of mm_modeling.py:21-30; the arithmetic replaced is the
+ * same nn.Linear forward / dX as fcmf_gemm.
+ *   fcmf_quant_fp8_rows: x [rows, K] (FCMF_BF16 / FCMF_F32, row stride ldx elements) -> q [rows, K] e4m3 bytes (row stride
+ *       ldq bytes) with one dequantisation scale per row: scale[r] = max|x[r, :]| / 448 (1 for a zero row),
+ *       q = rne(x / scale[r]).  K, ldx, ldq multiples of 8.
+ *   fcmf_gemm_fp8: C[M,N] bf16 = epilogue( (A_q[M,K] * B_q[N,K]^T) * sa[m] * sb[n] + bias[n] ); both operands K-contiguous
+ *       e4m3 with their row scales (A: activations / output gradients quantised per token; B: the weight quantised per output
+ *       row -- or its transposed copy per input row for dX).  Epilogues NONE / GELU / DGELU / ADD, aux and colsum as in
+ *       fcmf_gemm.  K % 128 == 0, lda / ldb % 16 == 0 (bytes), N and ldc % 8 == 0, M, N >= 256: otherwise
+ *       FCMF_ERR_UNSUPPORTED (the caller keeps the bf16 path). */
+int fcmf_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, int dtype, void* stream);
+int fcmf_gemm_fp8(fcmf_gemm_ctx* ctx, const void* A, const float* sa, const void* B, const float* sb, void* C,
+                  const float* bias, void* aux, float* colsum, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                  int epilogue, void* stream);
+
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X dtype = dtype, out float32. */
 int fcmf_colsum(const void* X, float* out, int M, int N, int64_t ldx, int dtype,
                 int accumulate, void* stream);

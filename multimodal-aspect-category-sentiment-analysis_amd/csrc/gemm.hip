@@ -1165,27 +1165,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tile192k64_kernel(GemmParams
   gemm_bf16_tile256_body<false, false, bf16_t, EPI, 6, 64>(p);
 }
 
-// e4m3 operands (see the body): K % 128 == 0, bf16 output
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_fp8_tile256_kernel(GemmParams p) {
-  gemm_bf16_tile256_body<false, false, bf16_t, EPI, 8, 64, true>(p);
-}
+// e4m3 operands (see the body): K % 128 == 0, bf16 output.  192 x 256 block tile only: with 256 rows the wave's 128 accumulator
+// registers + 64 fragment registers (32 bytes per fragment) + DMA offsets exceed 256 VGPRs and the main loop reloads from
+// scratch (VMEM operations in the counted-vmcnt DMA pipeline); the 192-row tile (96 accumulators) compiles to 226 VGPRs, no scratch.
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_fp8_tile192_kernel(GemmParams p) {
   gemm_bf16_tile256_body<false, false, bf16_t, EPI, 6, 64, true>(p);
 }
 template <int EPI>
-static void launch_fp8_tile(const GemmParams& p, dim3 grid, hipStream_t st, int tm) {
+static void launch_fp8_tile(const GemmParams& p, dim3 grid, hipStream_t st) {
   const size_t smem = (size_t)RING_BYTES + 8 * 4096;
-  if (tm == 192) {
-    auto k = gemm_fp8_tile192_kernel<EPI>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
-  } else {
-    auto k = gemm_fp8_tile256_kernel<EPI>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
-  }
+  auto k = gemm_fp8_tile192_kernel<EPI>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
 }
 
 template <bool A_TR, bool B_TR, typename TC, int EPI>
@@ -1448,12 +1440,7 @@ extern "C" int fcmf_gemm_fp8(fcmf_gemm_ctx* ctx, const void* A, const float* sa,
   p.b_bytes = (unsigned)(((int64_t)N - 1) * ldb + K);
   p.c_bytes = (unsigned)c_extent;
   const int slots = cfg.num_cus, nk = K / 128;
-  int tm = 256;
-  auto cost = [&](int rows) {
-    const int64_t t = (int64_t)((M + rows - 1) / rows) * ((N + GB - 1) / GB);
-    return (double)((t + slots - 1) / slots) * (2.0 * nk * (rows / 256.0) + 8.0);
-  };
-  if (cfg.force_tile == 192 || (cfg.force_tile == 0 && cost(192) < 0.97 * cost(256))) tm = 192;
+  constexpr int tm = 192;
   p.tiles = ((M + tm - 1) / tm) * ((N + GB - 1) / GB);
   p.ktiles_per_split = nk;
   p.ksplit = 1;
@@ -1466,10 +1453,10 @@ extern "C" int fcmf_gemm_fp8(fcmf_gemm_ctx* ctx, const void* A, const float* sa,
     snprintf(ctx->last_kernel, sizeof ctx->last_kernel, "gemm_fp8_tile%d_kernel<%s>", tm, epi_names[epilogue]);
   }
   switch (epilogue) {
-    case FCMF_EPI_NONE: launch_fp8_tile<FCMF_EPI_NONE>(p, grid, st, tm); break;
-    case FCMF_EPI_GELU: launch_fp8_tile<FCMF_EPI_GELU>(p, grid, st, tm); break;
-    case FCMF_EPI_DGELU: launch_fp8_tile<FCMF_EPI_DGELU>(p, grid, st, tm); break;
-    default: launch_fp8_tile<FCMF_EPI_ADD>(p, grid, st, tm); break;
+    case FCMF_EPI_NONE: launch_fp8_tile<FCMF_EPI_NONE>(p, grid, st); break;
+    case FCMF_EPI_GELU: launch_fp8_tile<FCMF_EPI_GELU>(p, grid, st); break;
+    case FCMF_EPI_DGELU: launch_fp8_tile<FCMF_EPI_DGELU>(p, grid, st); break;
+    default: launch_fp8_tile<FCMF_EPI_ADD>(p, grid, st); break;
   }
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;

@@ -205,13 +205,13 @@ def _post_fwd(c, res, res_ld, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2, eps, p, 
     I = w1.shape[0]
     co, c1, c2 = ops.as_compute(wo, dt), ops.as_compute(w1, dt), ops.as_compute(w2, dt)
     h = torch.empty((M, Hd), dtype=dt, device=c.device)
-    ops.gemm(c, co, h, M, Hd, Hd, Hd, Hd, Hd, 0, 0, bias=bo.detach())
+    ops.gemm_nt(c, wo, co, h, M, Hd, Hd, Hd, bias=bo.detach())
     h1, z1, m1, r1 = _ln_fwd(h, res, res_ld, g1, be1, eps, p, seeds[0])
     u = torch.empty((M, I), dtype=dt, device=c.device)
     a = torch.empty((M, I), dtype=dt, device=c.device)
-    ops.gemm(h1, c1, a, M, I, Hd, Hd, Hd, I, 0, 0, bias=b1.detach(), aux=u, epi=H.EPI_GELU)
+    ops.gemm_nt(h1, w1, c1, a, M, I, Hd, Hd, bias=b1.detach(), aux=u, epi=H.EPI_GELU)
     f = torch.empty((M, Hd), dtype=dt, device=c.device)
-    ops.gemm(a, c2, f, M, Hd, I, I, I, Hd, 0, 0, bias=b2.detach())
+    ops.gemm_nt(a, w2, c2, f, M, Hd, I, I, bias=b2.detach())
     y, z2, m2, r2 = _ln_fwd(f, h1, Hd, g2, be2, eps, p, seeds[1])
     return y, (z1, m1, r1, h1, u, a, z2, m2, r2)
 
@@ -312,7 +312,8 @@ class SelfLayerFn(torch.autograd.Function):
         wqkv = _fused_weight([wq, wk, wv], dt)
         bqkv = _fused_weight([bq, bk, bv], torch.float32)
         qkv = torch.empty((M, 3 * Hd), dtype=dt, device=x.device)
-        ops.gemm(x2, wqkv, qkv, M, 3 * Hd, Hd, Hd, Hd, 3 * Hd, 0, 0, bias=bqkv)
+        wm = _fused_weight([wq, wk, wv], torch.float32)             # the [3H, H] float32 view when the storage is fused
+        ops.gemm_nt(x2, wm if wm.data_ptr() == wq.data_ptr() else None, wqkv, qkv, M, 3 * Hd, Hd, Hd, bias=bqkv, owner=wq)
         mk = None if mask is None else mask.contiguous().float()
         c, lse = self_attention_fwd(qkv, mk, G_, T, Hd, heads, p_a, seed_a)
         y, saved = _post_fwd(c, x2, Hd, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2, eps, p_h, (seed0, seed1))

@@ -31,6 +31,20 @@ def compute_dtype():
     return _compute_dtype
 
 
+_fp8 = False
+
+
+def set_fp8(on):
+    """BASELINE configs[4]: forward and dX GEMMs of the bf16 mode on e4m3 operands (per-row scales, float32 accumulation,
+    v_mfma_scale_f32_16x16x128_f8f6f4); weight gradients, attention, LayerNorm and the optimizer are unchanged"""
+    global _fp8
+    _fp8 = bool(on)
+
+
+def fp8_enabled():
+    return _fp8 and _compute_dtype == torch.bfloat16
+
+
 _seed_base = 0x5DEECE66D
 _seed_ctr = 0
 
@@ -61,6 +75,8 @@ class _Shadows:
         self.pad = {}
         self.mapT = {}
         self.mapD = {}
+        self.mapQ = {}
+        self.mapQT = {}
         self._mt_tables = None
 
     def get_t(self, w, owner=None):
@@ -123,6 +139,32 @@ class _Shadows:
             ent[2] = False
             ent[1] = ent[4]()._version       # fresh as of the owner's current version
 
+    def get_fp8(self, w, owner=None):
+        """(q [N, K] e4m3 bytes, scale [N] float32) of a float32 [N, K] weight, quantised per output row; rebuilt lazily
+        after the parameter changed (FusedAdamW marks every shadow stale)"""
+        key = (w.data_ptr(), tuple(w.shape))
+        ent = self.mapQ.get(key)
+        owner = w if owner is None else owner
+        if ent is not None and ent[1] == w._version and not ent[2] and ent[3]() is owner:
+            return ent[0]
+        src = self.get(w) if w.is_contiguous() else w.detach().contiguous()       # the bf16 shadow: half the bytes to read
+        q, sc = quant_fp8_rows(src, w.shape[0], w.shape[1], w.shape[1], out=None if ent is None else ent[0])
+        self.mapQ[key] = [(q, sc), w._version, False, weakref.ref(owner)]
+        return q, sc
+
+    def get_fp8_t(self, w, owner=None):
+        """(q [K, N] e4m3, scale [K]) of the TRANSPOSE of a float32 [N, K] weight, quantised per input row: the B operand
+        of dX = dY W on the fp8 kernel (contraction over N)"""
+        key = (w.data_ptr(), tuple(w.shape))
+        ent = self.mapQT.get(key)
+        owner = w if owner is None else owner
+        if ent is not None and ent[1] == w._version and not ent[2] and ent[3]() is owner:
+            return ent[0]
+        wt = self.get_t(w, owner)                                                   # [K, N] bf16, fresh
+        q, sc = quant_fp8_rows(wt, wt.shape[0], wt.shape[1], wt.shape[1], out=None if ent is None else ent[0])
+        self.mapQT[key] = [(q, sc), w._version, False, weakref.ref(owner)]
+        return q, sc
+
     def padded(self, w):
         """the fresh bf16 copy of a 2-D weight including its zero rows up to a multiple of 32"""
         sh = self.get(w)
@@ -180,12 +222,19 @@ class _Shadows:
             ent[2] = True
         for ent in self.mapD.values():
             ent[2] = True
+        for m in (self.mapQ, self.mapQT):
+            for k in [k for k, ent in m.items() if ent[3]() is None]:      # quantised copies of freed weights
+                del m[k]
+            for ent in m.values():
+                ent[2] = True
 
     def clear(self):
         self.map.clear()
         self.pad.clear()
         self.mapT.clear()
         self.mapD.clear()
+        self.mapQ.clear()
+        self.mapQT.clear()
         self._mt_tables = None
 
 
@@ -305,6 +354,47 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI
         _gemm_trace.append((H.lib().fcmf_gemm_ctx_last_kernel(ctx).decode(), 2.0 * M * N * K, e0, e1))
 
 
+def quant_fp8_rows(x, rows, K, ldx, out=None):
+    """x [rows, K] (bf16 / f32 rows at stride ldx) -> (q [rows, K] uint8 e4m3, scale [rows] float32) through fcmf_quant_fp8_rows"""
+    H.require_cuda(x)
+    if out is None:
+        q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+        sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    else:
+        q, sc = out
+    H.check(H.lib().fcmf_quant_fp8_rows(H.ptr(x), ldx, H.ptr(q), K, H.ptr(sc), rows, K, H.dt(x), H.stream()), "fcmf_quant_fp8_rows")
+    return q, sc
+
+
+def _fp8_ok(M, N, K, ldc, *tensors):
+    return (fp8_enabled() and K % 128 == 0 and N % 8 == 0 and ldc % 8 == 0 and M >= 256 and N >= 256
+            and all(t is None or t.dtype == torch.bfloat16 for t in tensors))
+
+
+def gemm_fp8(xq, sx, wq, sw, C, M, N, K, bias=None, aux=None, epi=H.EPI_NONE, colsum=None):
+    ctx = H.gemm_ctx()
+    if _gemm_trace is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    H.check(H.lib().fcmf_gemm_fp8(ctx, H.ptr(xq), H.ptr(sx), H.ptr(wq), H.ptr(sw), H.ptr(C), H.ptr(bias), H.ptr(aux), H.ptr(colsum),
+                                  M, N, K, K, K, N, epi, H.stream()), "fcmf_gemm_fp8")
+    if _gemm_trace is not None:
+        e1.record()
+        _gemm_trace.append((H.lib().fcmf_gemm_ctx_last_kernel(ctx).decode(), 2.0 * M * N * K, e0, e1))
+
+
+def gemm_nt(x, weight, w_compute, y, M, N, K, ldx, bias=None, aux=None, epi=H.EPI_NONE, colsum=None, owner=None):
+    """y [M, N] = epilogue(x [M, K] W^T + bias), W [N, K]: the forward GEMM of nn.Linear.  `weight` = the float32 master (or a
+    view of it; `owner` = its Parameter) when there is one: the fp8 mode then multiplies e4m3 copies (x quantised per row here,
+    W per output row, cached); otherwise the bf16 / f32 kernel on `w_compute`."""
+    if weight is not None and weight.dtype == torch.float32 and weight.dim() == 2 and _fp8_ok(M, N, K, N, x, y, aux):
+        xq, sx = quant_fp8_rows(x, M, K, ldx)
+        wq, sw = shadows.get_fp8(weight, owner)
+        gemm_fp8(xq, sx, wq, sw, y, M, N, K, bias=bias, aux=aux, epi=epi, colsum=colsum)
+    else:
+        gemm(x, w_compute, y, M, N, K, ldx, K, N, 0, 0, bias=bias, aux=aux, epi=epi, colsum=colsum)
+
+
 def colsum(X, M, N, ldx):
     out = torch.empty(N, dtype=torch.float32, device=X.device)
     H.check(H.lib().fcmf_colsum(H.ptr(X), H.ptr(out), M, N, ldx, H.dt(X), 0, H.stream()), "fcmf_colsum")
@@ -318,7 +408,12 @@ def _ld(x):
 def gemm_dx(dy, weight, w_compute, dx, M, K_in, N_out, aux=None, epi=H.EPI_NONE, colsum=None, owner=None):
     """dx [M,K_in] = dy [M,N_out] @ W [N_out,K_in] (+ epilogue).  bf16 mode multiplies by the transposed bf16 copy of the
     float32 master `weight` (an NT GEMM); f32 mode, or a weight without a master, uses `w_compute` as it lies (NN)."""
-    if dy.dtype == torch.bfloat16 and weight is not None and weight.dtype == torch.float32 and weight.dim() == 2:
+    if (weight is not None and weight.dtype == torch.float32 and weight.dim() == 2 and dy.is_contiguous()
+            and _fp8_ok(M, K_in, N_out, K_in, dy, dx, aux)):
+        dyq, sdy = quant_fp8_rows(dy, M, N_out, N_out)
+        wq, sw = shadows.get_fp8_t(weight, owner)                    # [K_in, N_out] e4m3, scales per input row
+        gemm_fp8(dyq, sdy, wq, sw, dx, M, K_in, N_out, aux=aux, epi=epi, colsum=colsum)
+    elif dy.dtype == torch.bfloat16 and weight is not None and weight.dtype == torch.float32 and weight.dim() == 2:
         wt = shadows.get_t(weight, owner)                            # [K_in, N_out]; owner: the Parameter behind a temporary view
         gemm(dy, wt, dx, M, K_in, N_out, N_out, N_out, K_in, 0, 0, aux=aux, epi=epi, colsum=colsum)
     else:
@@ -338,11 +433,14 @@ def gemm_dx_long_k(dy, w, M, K_in, N_out, ldw):
     return cast(dx32, torch.bfloat16)
 
 
-def _linear_fwd(x, w, bias, epi=H.EPI_NONE, aux=None):
+def _linear_fwd(x, w, bias, epi=H.EPI_NONE, aux=None, master=None):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    gemm(x, w, y, M, N, K, _ld(x), K, N, 0, 0, bias=bias, aux=aux, epi=epi)
+    if epi == H.EPI_TANH or master is None:
+        gemm(x, w, y, M, N, K, _ld(x), K, N, 0, 0, bias=bias, aux=aux, epi=epi)
+    else:
+        gemm_nt(x, master, w, y, M, N, K, _ld(x), bias=bias, aux=aux, epi=epi)
     return y
 
 
@@ -373,7 +471,7 @@ class LinearFn(torch.autograd.Function):
         x2 = _rows(x)
         w = as_compute(weight, x2.dtype)
         epi = H.EPI_TANH if act == "tanh" else H.EPI_NONE
-        y = _linear_fwd(x2, w, None if bias is None else bias.detach(), epi)
+        y = _linear_fwd(x2, w, None if bias is None else bias.detach(), epi, master=weight)
         ctx.save_for_backward(x2, weight, y if act == "tanh" else None)
         ctx.act = act
         ctx.has_bias = bias is not None
@@ -575,8 +673,8 @@ class FFNFn(torch.autograd.Function):
         c1, c2 = as_compute(w1, x2.dtype), as_compute(w2, x2.dtype)
         M = x2.shape[0]
         u = torch.empty((M, w1.shape[0]), dtype=x2.dtype, device=x2.device)
-        a = _linear_fwd(x2, c1, b1.detach(), H.EPI_GELU, aux=u)
-        y = _linear_fwd(a, c2, b2.detach())
+        a = _linear_fwd(x2, c1, b1.detach(), H.EPI_GELU, aux=u, master=w1)
+        y = _linear_fwd(a, c2, b2.detach(), master=w2)
         ctx.save_for_backward(x2, w1, w2, u, a)
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], w2.shape[0])

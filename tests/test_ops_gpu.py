@@ -914,3 +914,134 @@ def test_dp_allreduce_bucket_c_abi_single_rank(dev):
     assert L.fcmf_dp_allreduce_bucket(h, H.ptr(buf), 4, H.F64, 1, 0) == -3            # unsupported dtype
     assert L.fcmf_dp_comm_create(ctypes.byref(ctypes.c_void_p()), ctypes.cast(uid, ctypes.c_void_p), 2, 5) == -1
     H.check(L.fcmf_dp_comm_destroy(h), "fcmf_dp_comm_destroy")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp8 (e4m3) path of BASELINE configs[4]
+# ---------------------------------------------------------------------------------------------------------------------
+def _e4m3_decode(q):
+    """uint8 e4m3fn bytes -> float32 (host restatement of the OCP format: bias 7, no infinities, 0x7F / 0xFF = NaN)"""
+    q = q.cpu().to(torch.int32)
+    sgn, e, m = (q >> 7) & 1, (q >> 3) & 15, q & 7
+    mag = torch.where(e == 0, m.float() * 2.0 ** -9, (1.0 + m.float() / 8.0) * torch.pow(2.0, (e - 7).float()))
+    return torch.where(sgn == 1, -mag, mag)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_quant_fp8_rows_matches_torch_float8(dev, dtype):
+    """fcmf_quant_fp8_rows: scale = amax / 448 per row, round-to-nearest-even onto OCP e4m3fn -- bit for bit what
+    torch's float8_e4m3fn cast gives for the same scaled values (zero rows, one huge outlier, ragged row count)"""
+    ops, H = _ops()
+    rows, K = 1003, 384
+    x = _rand((rows, K), dev, dtype, 3.0, seed=1)
+    x[5] = 0
+    x[7, 11] = 3.0e4
+    x[9] *= 1e-6
+    q, sc = ops.quant_fp8_rows(x, rows, K, K)
+    xf = x.float().cpu()
+    amax = xf.abs().amax(1)
+    want_sc = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    assert torch.allclose(sc.cpu(), want_sc, rtol=1e-6, atol=0)
+    ref = (xf * (1.0 / sc.cpu())[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    got = q.cpu()
+    same = (got == ref) | (((got & 0x7F) == 0) & ((ref & 0x7F) == 0))            # +0 / -0
+    assert same.all(), (same.numel() - same.sum().item())
+    assert (_e4m3_decode(got).abs().amax(1)[amax > 0] == 448.0).all()           # every non-zero row uses the full range
+    assert torch.equal(_e4m3_decode(ref), ref.view(torch.float8_e4m3fn).float())   # (the decoder itself against torch)
+
+
+@pytest.mark.parametrize("epi", ["none", "gelu", "dgelu", "add"])
+@pytest.mark.parametrize("M,N,K", [(1000, 776, 384), (4416, 4104, 128), (6144, 1024, 1024), (300, 256, 2048)])
+def test_gemm_fp8_matches_dequantised_reference(dev, M, N, K, epi):
+    """fcmf_gemm_fp8 on v_mfma_scale_f32_16x16x128_f8f6f4 against the SAME quantised operands multiplied in float64: pins the
+    operand layout (32 consecutive k per lane group through the permuted LDS image), the unit block scales, the row-scale
+    epilogue and every fused epilogue, on ragged M / N edges and 1..16 k-tiles.  Tolerance = float32 accumulation + the bf16
+    rounding of the output."""
+    ops, H = _ops()
+    A, W = _rand((M, K), dev, torch.bfloat16, 1.0, seed=1), _rand((N, K), dev, torch.bfloat16, 0.2, seed=2)
+    bias = _rand((N,), dev, seed=3)
+    u = _rand((M, N), dev, torch.bfloat16, 1.5, seed=5)
+    aq, sa = ops.quant_fp8_rows(A, M, K, K)
+    wq, sw = ops.quant_fp8_rows(W, N, K, K)
+    ref = (_e4m3_decode(aq).double() @ _e4m3_decode(wq).double().t()) * sa.cpu().double()[:, None] * sw.cpu().double()[None, :]
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    aux = torch.empty_like(C)
+    cs = torch.zeros(N, dtype=torch.float32, device=dev)
+    uf = u.float().cpu().double()
+    if epi == "none":
+        ops.gemm_fp8(aq, sa, wq, sw, C, M, N, K, bias=bias, colsum=cs)
+        want = ref + bias.cpu().double()
+    elif epi == "gelu":
+        ops.gemm_fp8(aq, sa, wq, sw, C, M, N, K, bias=bias, aux=aux, epi=H.EPI_GELU)
+        pre = ref + bias.cpu().double()
+        assert rel_err(aux, pre.float()) < 1e-2
+        want = torch.nn.functional.gelu(pre)
+    elif epi == "dgelu":
+        ops.gemm_fp8(aq, sa, wq, sw, C, M, N, K, aux=u, epi=H.EPI_DGELU, colsum=cs)
+        phi = 0.5 * (1 + torch.erf(uf / 2 ** 0.5))
+        want = ref * (phi + uf * torch.exp(-0.5 * uf * uf) / (2 * 3.141592653589793) ** 0.5)
+    else:
+        ops.gemm_fp8(aq, sa, wq, sw, C, M, N, K, bias=bias, aux=u, epi=H.EPI_ADD)
+        want = ref + bias.cpu().double() + uf
+    assert H.last_gemm_kernel().startswith("gemm_fp8_tile192_kernel")
+    assert rel_err(C, want.float()) < 1e-2, rel_err(C, want.float())           # bf16 output rounding (2^-9) of O(1) values
+    if epi in ("none", "dgelu"):
+        assert rel_err(cs, C.float().cpu().sum(0)) < 2e-3
+    # and against the UNquantised product: the e4m3 quantisation noise itself (3 mantissa bits per operand, averaged over K)
+    exact = A.float().cpu().double() @ W.float().cpu().double().t()
+    noise = ((ref - exact).norm() / exact.norm()).item()
+    assert noise < 6e-2, noise
+
+
+def test_fp8_linear_layers_forward_backward(dev):
+    """ops.set_fp8(True): nn.Linear forward and dX run on the e4m3 kernel (dW stays bf16), through the autograd Functions the
+    model uses (LinearFn, FFNFn): against the float64 reference within e4m3 quantisation noise, and the quantised weight copies
+    follow the parameter (rebuilt after an optimizer step)"""
+    ops, H = _ops()
+    from fcmf_framework.optimization import FusedAdamW
+    M, Hd, I = 2048, 1024, 4096
+    ops.set_compute_dtype(torch.bfloat16)
+    ops.shadows.clear()
+    try:
+        x0 = _rand((M, Hd), dev, torch.bfloat16, 1.0, seed=1)
+        w1, b1 = torch.nn.Parameter(_rand((I, Hd), dev, scale=0.03, seed=2)), torch.nn.Parameter(_rand((I,), dev, scale=0.1, seed=3))
+        w2, b2 = torch.nn.Parameter(_rand((Hd, I), dev, scale=0.03, seed=4)), torch.nn.Parameter(_rand((Hd,), dev, scale=0.1, seed=5))
+        g = _rand((M, Hd), dev, torch.bfloat16, 1.0, seed=6)
+
+        def run(fp8):
+            ops.set_fp8(fp8)
+            for p in (w1, b1, w2, b2):
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = ops.ffn(x, w1, b1, w2, b2)
+            names = []
+            ops.gemm_trace_begin()
+            y2 = ops.ffn(x, w1, b1, w2, b2)
+            (y2.float() * g.float()).sum().backward()
+            names = [n for n, _, _ in ops.gemm_trace_end()]
+            return y.detach().float().cpu(), x.grad.float().cpu(), w1.grad.float().cpu(), w2.grad.float().cpu(), names
+        y8, dx8, dw1_8, dw2_8, n8 = run(True)
+        y16, dx16, dw1_16, dw2_16, n16 = run(False)
+        assert sum(n.startswith("gemm_fp8") for n in n8) == 4 and not any(n.startswith("gemm_fp8") for n in n16)   # 2 fwd + 2 dX
+        assert sum("f32" in n for n in n8) == 2                                                                     # dW: bf16 operands
+        xd, w1d, w2d = x0.float().cpu().double(), w1.detach().cpu().double(), w2.detach().cpu().double()
+        pre = xd @ w1d.t() + b1.detach().cpu().double()
+        yref = torch.nn.functional.gelu(pre) @ w2d.t() + b2.detach().cpu().double()
+        e8, e16 = ((y8 - yref).norm() / yref.norm()).item(), ((y16 - yref).norm() / yref.norm()).item()
+        assert e16 < 1e-2 and e8 < 6e-2, (e8, e16)
+        for a8, a16, nm in ((dx8, dx16, "dx"), (dw1_8, dw1_16, "dw1"), (dw2_8, dw2_16, "dw2")):
+            r = ((a8 - a16).norm() / a16.norm()).item()
+            assert r < 8e-2, (nm, r)
+        # the quantised copies follow the parameter
+        ops.set_fp8(True)
+        q_before = ops.shadows.get_fp8(w1)[0].clone()
+        opt = FusedAdamW([w1, b1, w2, b2], lr=1e-2)
+        opt.step()
+        assert not torch.equal(ops.shadows.get_fp8(w1)[0], q_before)
+        q, sc = ops.shadows.get_fp8(w1)
+        q2, sc2 = ops.quant_fp8_rows(w1.detach().bfloat16(), I, Hd, Hd)
+        assert torch.equal(q, q2) and torch.equal(sc, sc2)
+    finally:
+        ops.set_fp8(False)
+        ops.set_compute_dtype(torch.float32)
+        ops.shadows.clear()

@@ -603,7 +603,33 @@ def test_fcmf_large_geometry_bf16_and_fp32(dev):
                 assert p.grad is None
             else:
                 assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        g16 = _named_grads(model)
+        # ---- the fp8 path of configs[4]: forward + dX GEMMs on e4m3 operands (ops.set_fp8), same graph otherwise ------------
+        # Tolerance: e4m3 carries 3 mantissa bits (2^-4 per element, averaged over K >= 1024 per dot product, 24 layers deep);
+        # bound = 8 % of the logit magnitude against the fp32 ORACLE (measured: see the printed line), gradients against the
+        # bf16 graph of the same weights: per-model cosine >= 0.97.
+        from fcmf_framework import ops
+        ops.set_fp8(True)
+        model.zero_grad(set_to_none=True)
+        ops.gemm_trace_begin()
+        l8 = _run_aspects(model, b)
+        model.loss_aspects(l8, b["labels"]).backward()
+        names = [n for n, _, _ in ops.gemm_trace_end()]
+        nf8 = sum(n.startswith("gemm_fp8") for n in names)
+        assert nf8 >= 24 * 8 - 8, (nf8, len(names))            # 24 layers x (qkv, out, ffn1, ffn2) x (forward, dX), first-layer dX aside
+        e8 = max_err(l8[:, 0], ref)
+        assert e8 < 8e-2 * ref.abs().max().item(), (e8, ref.abs().max().item())
+        g8 = _named_grads(model)
+        keys = [n for n in g16 if not n.endswith(ZERO_GRAD) and g16[n].norm().item() > 0]
+        a = torch.cat([(g8[n] / (g16[n].norm() + 1e-30)).flatten() for n in keys])
+        r = torch.cat([(g16[n] / (g16[n].norm() + 1e-30)).flatten() for n in keys])
+        assert all(torch.isfinite(g8[n]).all() for n in keys)
+        assert _cos(a, r) > 0.97, _cos(a, r)
+        print(f"fcmf-large fp8: logits err vs fp32 oracle {e8:.3e} (|ref|max {ref.abs().max().item():.3f}; bf16: {max_err(l16[:, 0], ref):.3e}), "
+              f"{nf8} e4m3 GEMMs of {len(names)}, gradient cosine vs the bf16 graph {_cos(a, r):.5f}")
     finally:
+        from fcmf_framework import ops as _o
+        _o.set_fp8(False)
         _set(torch.float32)
         model.zero_grad(set_to_none=True)
 
