@@ -329,6 +329,17 @@ int fcmf_bn_finalize(const double* sums, const float* gamma, const float* beta, 
  * (bn -> relu, and the bottleneck's bn3 -> += identity -> relu) */
 int fcmf_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows,
                   int C, int64_t rows_per_group, int relu, int dtype, void* stream);
+/* the same with y an NHWC tensor that carries a zero border of `pad` pixels ([n, H + 2 pad, W + 2 pad, C], border zeroed once by
+ * its owner; rows = n * H * W): the input of an implicit-GEMM 3x3 convolution, produced without a padding pass */
+int fcmf_bn_apply_pad(const void* x, const void* res, void* y_padded, const float* scale, const float* shift,
+                      int64_t rows, int C, int64_t rows_per_group, int relu, int H, int W, int pad, int dtype, void* stream);
+/* Implicit-GEMM convolution (no patch matrix): y[(n, oy, ox), co] = sum_{ky,kx,c} x[n, oy*stride + ky, ox*stride + kx, c] * w[co, (ky,kx,c)]
+ * on the bf16 MFMA GEMM kernels -- the LDS-DMA of a k-tile reads tap (ky, kx) of every output pixel's receptive field straight
+ * from the NHWC activation x [n, Hp, Wp, C], which INCLUDES the zero border where the convolution pads (Hp = H + 2 pad).
+ * ResNet-152 trunk: every 3x3 convolution and the strided 1x1 shortcuts (resnet_utils.py:13-24 driving torchvision's Bottleneck);
+ * bf16, C a power of two >= 64, w [Cout, kh*kw*C] row-major in (ky, kx, c) order, y [n*Ho*Wo, Cout]. */
+int fcmf_conv_gemm(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int C, int Ho, int Wo,
+                   int kh, int kw, int stride, int Cout, void* stream);
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC: [N,H,W,C] -> [N,(H-1)/2+1,(W-1)/2+1,C] */
 int fcmf_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 /* F.adaptive_avg_pool2d(x, [oh, ow]) of an NHWC activation, float32 output: layout 0 = [N, C, oh, ow] (what

@@ -182,11 +182,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       int64_t rows, int C, int64_t rows_per_group, int relu) {
+                                                       int64_t rows, int C, int64_t rows_per_group, int relu, int H, int W, int pad) {
+  // pad > 0: y is an NHWC tensor WITH a zero border of `pad` pixels ([n, H + 2 pad, W + 2 pad, C]; the border was zeroed once
+  // by its owner): the input of an implicit-GEMM 3x3 convolution (fcmf_conv_gemm), written here without a padding pass
   const int C4 = C >> 2;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < rows * C4; idx += (int64_t)gridDim.x * 256) {
     const int64_t row = idx / C4;
     const int c = (int)(idx - row * C4) * 4;
+    int64_t orow = row;
+    if (pad > 0) {
+      const int w = (int)(row % W);
+      const int64_t t = row / W;
+      const int h = (int)(t % H);
+      orow = ((t / H) * (H + 2 * pad) + h + pad) * (W + 2 * pad) + w + pad;
+    }
     const int64_t g = row / rows_per_group;
     const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + c);
     const float4 sh = *reinterpret_cast<const float4*>(shift + g * C + c);
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    Vec4<T>::store(y + row * C + c, v);
+    Vec4<T>::store(y + orow * C + c, v);
   }
 }
 
@@ -530,14 +539,26 @@ extern "C" int fcmf_bn_finalize(const double* sums, const float* gamma, const fl
   return FCMF_OK;
 }
 
+static int bn_apply_impl(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows, int C,
+                         int64_t rows_per_group, int relu, int H, int W, int pad, int dtype, void* stream);
 extern "C" int fcmf_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,
                              int64_t rows, int C, int64_t rows_per_group, int relu, int dtype, void* stream) {
+  return bn_apply_impl(x, res, y, scale, shift, rows, C, rows_per_group, relu, 1, 1, 0, dtype, stream);
+}
+extern "C" int fcmf_bn_apply_pad(const void* x, const void* res, void* y_padded, const float* scale, const float* shift,
+                                 int64_t rows, int C, int64_t rows_per_group, int relu, int H, int W, int pad, int dtype,
+                                 void* stream) {
+  if (H <= 0 || W <= 0 || pad < 0 || rows % ((int64_t)H * W) != 0) return FCMF_ERR_ARG;
+  return bn_apply_impl(x, res, y_padded, scale, shift, rows, C, rows_per_group, relu, H, W, pad, dtype, stream);
+}
+static int bn_apply_impl(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows, int C,
+                         int64_t rows_per_group, int relu, int H, int W, int pad, int dtype, void* stream) {
   if (!x || !y || !scale || !shift || rows < 0 || C <= 0 || C % 4 != 0 || rows_per_group <= 0) return FCMF_ERR_ARG;
   if (rows == 0) return FCMF_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int g = grid_for(rows * (C / 4));
-  if (dtype == FCMF_F32) hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)res, (float*)y, scale, shift, rows, C, rows_per_group, relu);
-  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, scale, shift, rows, C, rows_per_group, relu);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)res, (float*)y, scale, shift, rows, C, rows_per_group, relu, H, W, pad);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, scale, shift, rows, C, rows_per_group, relu, H, W, pad);
   else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;

@@ -22,7 +22,22 @@ struct GemmParams {
   float* ws;                   // split-K partial tiles [ksplit][M][N] (plain stores + a reduce pass) or null (float atomics)
   int nt_out;                  // bf16 epilogue: nontemporal stores (streamed outputs must not evict the operands from L2)
   const float* sa; const float* sb;   // fp8 kernels: per-row dequantisation scales of A [M] and of B [N]
+  // implicit-GEMM convolution (cv_C > 0): A is an NHWC activation [n, Hp, Wp, C] (zero border included where the convolution
+  // pads), row m = output pixel (n, oy, ox), k = (ky, kx, c).  C is a power of two and a multiple of the k-tile depth.
+  int cv_C, cv_logC, cv_Hp, cv_Wp, cv_Ho, cv_Wo, cv_kw, cv_inv_kw, cv_stride;
 };
+
+// element offset of the receptive-field origin of output row `row` in the (padded) input
+__device__ __forceinline__ int64_t conv_row_base(const GemmParams& p, int row) {
+  const int hw = p.cv_Ho * p.cv_Wo, n = row / hw, rem = row - n * hw, oy = rem / p.cv_Wo, ox = rem - oy * p.cv_Wo;
+  return (((int64_t)n * p.cv_Hp + oy * p.cv_stride) * p.cv_Wp + ox * p.cv_stride) << p.cv_logC;
+}
+// byte offset (wave-uniform: the DMA's scalar offset) of the k-tile that starts at contraction index kk: tap (ky, kx), channel c0
+__device__ __forceinline__ unsigned conv_k_offset(const GemmParams& p, int kk) {
+  const int tap = kk >> p.cv_logC, c0 = kk & (p.cv_C - 1);
+  const int ky = (tap * p.cv_inv_kw) >> 16, kx = tap - ky * p.cv_kw;
+  return (unsigned)((((ky * p.cv_Wp + kx) << p.cv_logC) + c0) * 2);
+}
 
 // bf16-output epilogues use odd polynomials instead of erf/exp (no transcendental issue slots, no
 // selects): with xc = clamp(x, -X, X),
@@ -205,6 +220,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   for (int j = 0; j < 2; ++j) {
     va[j] = dma_voffset<A_TR>(wave, j, lane, p.lda, i0, p.M);
     vb[j] = dma_voffset<B_TR>(wave, j, lane, p.ldb, j0, p.N);
+    if constexpr (!A_TR) {
+      if (p.cv_C) {              // implicit-GEMM convolution: the row's offset is that of its receptive field
+        const int q = (wave * 2 + j) * 64 + lane, row = q >> 2, c = (q & 3) ^ swz_row(row);
+        va[j] = i0 + row < p.M ? (unsigned)((conv_row_base(p, i0 + row) + c * 8) * 2) : 0x80000000u;
+      }
+    }
   }
   // per-k-tile advance: K-contiguous operands move by BK elements (scalar offset), transposed
   // operands by BK rows (added to the per-lane offset so that the range check sees it)
@@ -215,7 +236,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   [[maybe_unused]] const u32x4 wA = rsrc_words(p.A, p.a_bytes), wB = rsrc_words(p.B, p.b_bytes);
   auto issue = [&](int t) {   // k-tile index relative to kt_begin -> ring stage t & 3
     char* st = smem + (t & (NSTAGE - 1)) * STAGE_BYTES + (wave * 2) * 1024;
-    const unsigned ka = (unsigned)(kt_begin + t) * a_step, kb = (unsigned)(kt_begin + t) * b_step;
+    const unsigned ka = (!A_TR && p.cv_C) ? conv_k_offset(p, (kt_begin + t) * BK) : (unsigned)(kt_begin + t) * a_step;
+    const unsigned kb = (unsigned)(kt_begin + t) * b_step;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if constexpr (ASM_DMA) {
@@ -369,8 +391,13 @@ __device__ __forceinline__ int swz_row64(int r) { return (r >> 1) & 7; }
 //           (physical chunk (g ^ swizzle) and the same + 4: conflict-free ds_read_b128 pairs), i.e. logical chunk
 //           c = 2g + h lives at physical chunk (g | h << 2) ^ swizzle.
 template <bool TR, int KB, bool FP8 = false>
-__device__ __forceinline__ unsigned dma_voffset_t(int piece, int lane, int64_t ld, int x0, int xdim) {
+__device__ __forceinline__ unsigned dma_voffset_t(int piece, int lane, int64_t ld, int x0, int xdim, const GemmParams* cv = nullptr) {
   const int q = piece * 64 + lane;             // 16-B slot inside the operand tile
+  if (!TR && !FP8 && cv) {                     // implicit-GEMM convolution (A operand): row -> receptive-field origin
+    const int row = KB == 32 ? q >> 2 : q >> 3, c = KB == 32 ? (q & 3) ^ swz_row(row) : (q & 7) ^ swz_row64(row);
+    if (x0 + row >= xdim) return 0x80000000u;
+    return (unsigned)((conv_row_base(*cv, x0 + row) + c * 8) * 2);
+  }
   if constexpr (FP8) {
     static_assert(!TR && KB == 64, "fp8 tiles: K-contiguous operands, 128-byte rows");
     const int row = q >> 3, x = (q & 7) ^ swz_row64(row), c = ((x & 3) << 1) | (x >> 2);
@@ -514,14 +541,15 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   auto sources = [&](const Item& w) -> Src {
     Src r;
 #pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR, KB, FP8>(a_piece0 + j, lane, p.lda, w.i0, p.M);
+    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR, KB, FP8>(a_piece0 + j, lane, p.lda, w.i0, p.M, p.cv_C ? &p : nullptr);
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR, KB, FP8>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
     return r;
   };
   // DMA of k-tile t of item w: A tile to sa and / or B tile to sb (nullptr = skip)
   auto issue_ab = [&](const Item& w, const Src& src, int t, char* sa, char* sb) {
-    const unsigned ka = (unsigned)(w.kt_begin + t) * a_step, kb = (unsigned)(w.kt_begin + t) * b_step;
+    const unsigned ka = (!A_TR && !FP8 && p.cv_C) ? conv_k_offset(p, (w.kt_begin + t) * KB) : (unsigned)(w.kt_begin + t) * a_step;
+    const unsigned kb = (unsigned)(w.kt_begin + t) * b_step;
     if (sa) {
 #pragma unroll
       for (int j = 0; j < A_PIECES; ++j) {
@@ -1284,9 +1312,11 @@ extern "C" int fcmf_gemm_ctx_tune(fcmf_gemm_ctx* ctx, int force_tile, int kb, in
 }
 extern "C" const char* fcmf_gemm_ctx_last_kernel(const fcmf_gemm_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
 
-extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
-                         int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
-                         int out_dtype, int epilogue, int accumulate, void* stream) {
+struct ConvGeom { int C, logC, Hp, Wp, Ho, Wo, kw, stride; int64_t in_bytes; };
+
+static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
+                     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
+                     int out_dtype, int epilogue, int accumulate, void* stream, const ConvGeom* cv) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0) return FCMF_ERR_ARG;
   const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
   char name_sink[96];
@@ -1310,9 +1340,11 @@ extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void*
                     (trans_a || K % BK == 0) && (trans_b || K % BK == 0) &&
                     (((int64_t)(trans_a ? K : M) * lda) < (1ll << 30)) && (((int64_t)(trans_b ? K : N) * ldb) < (1ll << 30));
   if (fast) {
-    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, nullptr, nullptr};
+    GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, nullptr, nullptr,
+                 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (cv) { p.cv_C = cv->C; p.cv_logC = cv->logC; p.cv_Hp = cv->Hp; p.cv_Wp = cv->Wp; p.cv_Ho = cv->Ho; p.cv_Wo = cv->Wo; p.cv_kw = cv->kw; p.cv_inv_kw = (65536 + cv->kw - 1) / cv->kw; p.cv_stride = cv->stride; }
     // bytes addressable through each operand: (rows - 1) * ld + contiguous extent
-    p.a_bytes = (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
+    p.a_bytes = cv ? (unsigned)cv->in_bytes : (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
     p.b_bytes = (unsigned)((((int64_t)(trans_b ? K : N) - 1) * ldb + (trans_b ? N : K)) * 2);
     const int64_t c_extent = (((int64_t)M - 1) * ldc + N) * 2;
     p.c_bytes = (unsigned)(c_extent < (1ll << 31) ? c_extent : 0);
@@ -1402,6 +1434,7 @@ extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void*
     if (trans_a && !trans_b) return launch_bf16<true, false>(p, out_dtype, grid, st);
     return launch_bf16<true, true>(p, out_dtype, grid, st);
   }
+  if (cv) return FCMF_ERR_UNSUPPORTED;      // (the any-stride kernel has no implicit-convolution addressing)
   GenericParams g{A, B, C, bias, aux, M, N, K,
                   trans_a ? 1 : lda, trans_a ? lda : 1, trans_b ? 1 : ldb, trans_b ? ldb : 1, ldc,
                   epilogue, accumulate, colsum};
@@ -1435,7 +1468,7 @@ extern "C" int fcmf_gemm_fp8(fcmf_gemm_ctx* ctx, const void* A, const float* sa,
       (int64_t)N * ldb >= (1ll << 31) || M < 256 || N < 256)
     return FCMF_ERR_UNSUPPORTED;
   const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
-  GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, 0, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, sa, sb};
+  GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, 0, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, sa, sb, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   p.a_bytes = (unsigned)(((int64_t)M - 1) * lda + K);
   p.b_bytes = (unsigned)(((int64_t)N - 1) * ldb + K);
   p.c_bytes = (unsigned)c_extent;
@@ -1492,6 +1525,46 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const T* __restrict
   }
 }
 
+// bf16 rows of up to 512 * NV elements held in registers: the row is read ONCE (16-byte loads, all in flight), then amax -> scale
+// -> convert -> 8-byte stores.  (The two-pass kernel above re-reads the row; at [24576, 4096] that second pass misses L2.)
+template <int NV>
+__global__ __launch_bounds__(256) void quant_fp8_rows_reg_kernel(const bf16_t* __restrict__ x, int64_t ldx, unsigned char* __restrict__ q,
+                                                                 int64_t ldq, float* __restrict__ scale, int rows, int K) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  bf16x8 v[NV];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int k = (lane + 64 * i) * 8;
+    if (k < K) v[i] = *reinterpret_cast<const bf16x8*>(xr + k);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if ((lane + 64 * i) * 8 < K) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[i][e]));
+    }
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f, inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  unsigned char* qr = q + (int64_t)row * ldq;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int k = (lane + 64 * i) * 8;
+    if (k < K) {
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][0] * inv, (float)v[i][1] * inv, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][2] * inv, (float)v[i][3] * inv, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][4] * inv, (float)v[i][5] * inv, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][6] * inv, (float)v[i][7] * inv, hi, true);
+      *reinterpret_cast<int2*>(qr + k) = make_int2(lo, hi);
+    }
+  }
+}
+
 extern "C" int fcmf_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, int dtype,
                                    void* stream) {
   if (!x || !q || !scale || rows < 0 || K <= 0) return FCMF_ERR_ARG;
@@ -1499,11 +1572,43 @@ extern "C" int fcmf_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t 
   if (rows == 0) return FCMF_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((rows + 3) / 4);
-  if (dtype == FCMF_BF16) hipLaunchKernelGGL((quant_fp8_rows_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, (unsigned char*)q, ldq, scale, rows, K);
+#define FCMF_QREG(NV) hipLaunchKernelGGL((quant_fp8_rows_reg_kernel<NV>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, (unsigned char*)q, ldq, scale, rows, K)
+  if (dtype == FCMF_BF16 && K <= 4096) {
+    if (K <= 512) FCMF_QREG(1); else if (K <= 1024) FCMF_QREG(2); else if (K <= 2048) FCMF_QREG(4); else FCMF_QREG(8);
+  } else if (dtype == FCMF_BF16) hipLaunchKernelGGL((quant_fp8_rows_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, (unsigned char*)q, ldq, scale, rows, K);
+#undef FCMF_QREG
   else if (dtype == FCMF_F32) hipLaunchKernelGGL((quant_fp8_rows_kernel<float>), grid, dim3(256), 0, st, (const float*)x, ldx, (unsigned char*)q, ldq, scale, rows, K);
   else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
+}
+
+extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
+                         int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
+                         int out_dtype, int epilogue, int accumulate, void* stream) {
+  return gemm_impl(ctx, A, B, C, bias, aux, colsum, M, N, K, lda, ldb, ldc, trans_a, trans_b, in_dtype, out_dtype, epilogue,
+                   accumulate, stream, nullptr);
+}
+
+// Implicit-GEMM convolution on the MFMA GEMM kernels: y[(n, oy, ox), co] = sum_{ky, kx, c} x[n, oy s + ky, ox s + kx, c] w[co, (ky, kx, c)].
+// x is the NHWC input INCLUDING its zero border ([n, Hp, Wp, C] with Hp = H + 2 pad: the producing kernel writes the interior,
+// fcmf_bn_apply with `pad`); no patch matrix exists: the LDS-DMA of A's k-tile t reads the tap (ky, kx) of every row's
+// receptive field straight from the activation (per-lane offset = the field's origin, fixed per work item; the tap is a
+// wave-uniform scalar offset).
+extern "C" int fcmf_conv_gemm(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int C, int Ho,
+                              int Wo, int kh, int kw, int stride, int Cout, void* stream) {
+  if (!x || !w || !y || n <= 0 || Hp <= 0 || Wp <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || Cout <= 0)
+    return FCMF_ERR_ARG;
+  if ((C & (C - 1)) || C < 64 || kh * kw > 64) return FCMF_ERR_UNSUPPORTED;             // k-tiles must not straddle taps
+  if ((Ho - 1) * stride + kh > Hp || (Wo - 1) * stride + kw > Wp) return FCMF_ERR_ARG;   // every tap inside the (padded) input
+  const int64_t in_bytes = (int64_t)n * Hp * Wp * C * 2, M = (int64_t)n * Ho * Wo;
+  if (in_bytes >= (1ll << 31) || M >= (1ll << 31)) return FCMF_ERR_UNSUPPORTED;
+  int logC = 0;
+  while ((1 << logC) < C) ++logC;
+  const ConvGeom cv{C, logC, Hp, Wp, Ho, Wo, kw, stride, in_bytes};
+  const int K = kh * kw * C;
+  return gemm_impl(ctx, x, w, y, nullptr, nullptr, nullptr, (int)M, Cout, K, K, K, Cout, 0, 0, FCMF_BF16, FCMF_BF16, FCMF_EPI_NONE, 0,
+                   stream, &cv);
 }
 
 extern "C" int fcmf_colsum(const void* X, float* out, int M, int N, int64_t ldx, int dtype, int accumulate,

@@ -81,6 +81,8 @@ SIGNATURES = {
     "fcmf_maxpool3x3s2_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "fcmf_adaptive_avgpool_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_bn_apply": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _vp],
+    "fcmf_bn_apply_pad": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _vp],
+    "fcmf_conv_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_maxpool3x3s2": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "fcmf_adaptive_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_dp_unique_id": [_vp],

@@ -246,3 +246,44 @@ def test_cpu_tensors_are_loud(dev):
     m, _ = _build(synth.RESNET_TINY_LAYERS, dev)
     with pytest.raises(HipLibraryError):
         myResNetImg(m, False, dev)(synth.synth_crops(1, 64))          # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("C,Cout,k,stride,N,hw", [(64, 64, 3, 1, 5, 14), (128, 128, 3, 2, 3, 28), (256, 256, 3, 1, 70, 14), (512, 512, 3, 2, 9, 14),
+                                                  (256, 512, 1, 2, 4, 56), (1024, 2048, 1, 2, 3, 14), (64, 64, 3, 1, 2, 56)])
+def test_implicit_gemm_convolution_matches_patch_matrix_and_torch(dev, C, Cout, k, stride, N, hw):
+    """fcmf_conv_gemm (no patch matrix: the GEMM's LDS-DMA walks the taps of every receptive field in the zero-bordered NHWC
+    activation) against (1) the explicit fcmf_conv_im2col + fcmf_gemm path on the same bf16 data -- same products, f32
+    accumulation in a different k order at most -- and (2) F.conv2d in float32; both the 128x128 kernel (Cout < 256) and
+    the persistent 256 / 192-row kernels (Cout >= 256, M x N large), stride 1 and 2, ragged row counts, 3x3 (padded input
+    written by fcmf_bn_apply_pad) and the strided 1x1 shortcut (unpadded input)."""
+    from fcmf_framework import _hip as H, ops, resnet as R
+    _set(torch.bfloat16)
+    try:
+        pad = 1 if k == 3 else 0
+        conv = R.Conv2d(C, Cout, k, stride=stride, padding=pad, bias=False).to(dev)
+        conv.weight.data = _rand(conv.weight.shape, 1, (2.0 / (C * k * k)) ** 0.5).to(dev)
+        x = _rand((N, hw, hw + 2, C), 2).to(dev).bfloat16()                      # NHWC
+        Hh, Ww = hw, hw + 2
+        Ho, Wo = (Hh + 2 * pad - k) // stride + 1, (Ww + 2 * pad - k) // stride + 1
+        with torch.no_grad():
+            R.IMPLICIT_CONV = False
+            y_exp = R.conv2d_nhwc(x, conv)
+            R.IMPLICIT_CONV = True
+            if k == 3:
+                # the producer's path: an identity BatchNorm-apply writes x into the interior of the zero-bordered buffer
+                xp = R.padded_activation(N, Hh, Ww, C, x.dtype, dev)
+                one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+                H.check(H.lib().fcmf_bn_apply_pad(H.ptr(x), None, H.ptr(xp), H.ptr(one), H.ptr(zero), N * Hh * Ww, C, N * Hh * Ww, 0, Hh, Ww, 1,
+                                                  H.dt(x), H.stream()), "fcmf_bn_apply_pad")
+                assert torch.equal(xp[:, 1:-1, 1:-1], x) and not xp[:, 0].any() and not xp[:, :, 0].any() and not xp[:, -1].any() and not xp[:, :, -1].any()
+                y_imp = R.conv2d_implicit(xp, conv, N, Ho, Wo)
+            else:
+                y_imp = R.conv2d_nhwc(x, conv)                                   # takes the implicit path by itself
+        assert y_imp.shape == y_exp.shape == (N, Ho, Wo, Cout)
+        scale = y_exp.float().abs().max().item()
+        assert max_err(y_imp, y_exp) <= 2 ** -7 * scale                           # one bf16 ulp of the largest value
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2).cpu(), conv.weight.data.float().cpu(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+        assert max_err(y_imp, ref) < 3e-2 * ref.abs().max().item()
+    finally:
+        R.IMPLICIT_CONV = True
+        _set(torch.float32)

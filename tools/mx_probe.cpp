@@ -2,7 +2,7 @@
 // the fp8 GEMM kernels of csrc/gemm_fp8.hip rely on, with exact arithmetic (small e4m3 values, power-of-two scales):
 //   A operand: lane l holds A[row = l & 15][k = 32 (l >> 4) + j], j = 0..31, byte j of its 8 VGPRs (little endian);
 //   B operand: lane l holds B[k = 32 (l >> 4) + j][col = l & 15];
-//   scale VGPRs: byte `opsel` of lane l's scale register = the E8M0 scale of ITS 32-element block (2^(e - 127));
+//   scale operands: E8M0 127 (= 2^0) for every block -- the product kernels apply their per-row scales in the epilogue;
 //   C/D: col = l & 15, row = 4 (l >> 4) + reg (as every 16x16 MFMA).
 //   hipcc -O2 --offload-arch=gfx950 tools/mx_probe.cpp -o tools/bin/mx_probe && tools/bin/mx_probe
 #include <hip/hip_runtime.h>
@@ -40,8 +40,9 @@ int main() {
   for (int trial = 0; trial < 8; ++trial) {
     for (auto& v : A) { v = rand() & 0xFF; if ((v & 0x7F) == 0x7F) v ^= 1; if (((v >> 3) & 15) > 9) v &= 0xC7 | (8 << 3) | 0x87; }
     for (auto& v : Bt) { v = rand() & 0xFF; if ((v & 0x7F) == 0x7F) v ^= 1; if (((v >> 3) & 15) > 9) v &= 0xC7 | (8 << 3) | 0x87; }
-    for (auto& v : sA) v = 120 + rand() % 12;
-    for (auto& v : sB) v = 122 + rand() % 10;
+    // unit block scales (E8M0 127 = 2^0) in every byte: what the product kernels pass; per-row scales live in their epilogue
+    for (auto& v : sA) v = 127;
+    for (auto& v : sB) v = 127;
     unsigned char *dA, *dB, *dsA, *dsB; float* dD;
     hipMalloc(&dA, A.size()); hipMalloc(&dB, Bt.size()); hipMalloc(&dsA, 64); hipMalloc(&dsB, 64); hipMalloc(&dD, 1024);
     hipMemcpy(dA, A.data(), A.size(), hipMemcpyHostToDevice); hipMemcpy(dB, Bt.data(), Bt.size(), hipMemcpyHostToDevice);
