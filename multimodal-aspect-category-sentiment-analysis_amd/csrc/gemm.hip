@@ -932,6 +932,21 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     // whole-row stores or 256-byte float atomics for split-K
     constexpr int LPR = GB / 8, RPI = 64 / LPR, RPW = 128 / NW;
     const bool to_ws = p.ws != nullptr && p.ksplit > 1;     // k-split partials go to the workspace with plain stores
+    if (to_ws && !p.bias && !p.colsum) {
+      // The workspace layout is ours to choose: the partial tile goes out in the FRAGMENT layout, straight from the accumulator
+      // registers -- every store instruction is one contiguous KiB (64 lanes x 16 B), no LDS staging, no barrier.  The reduce pass
+      // (splitk_reduce_frag_kernel) reads the partials back in the same order and only there maps (fragment, lane) to (row, column).
+      // (The row-layout path below staged 2 x 128 KiB through LDS between four barriers: ~35 us per work item of a 230 us dW.)
+      float* wsp = p.ws + ((int64_t)w.zsplit * p.tiles + (item - w.zsplit * p.tiles)) * (GB * GB) + (wave * 32 * 64 + lane) * 4;
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+          __builtin_nontemporal_store(acc[fj][fi], reinterpret_cast<f32x4*>(wsp + (fj * 8 + fi) * 256));
+      base = (base + nkt) & (TNST - 1);
+      continue;                                   // (barrier-free, like the bf16 epilogue: the next item's tiles 0-2 go to the three
+                                                  //  stages every wave has finished reading; the fourth waits for ITS barrier 0)
+    }
     const bool atomic = (p.ksplit > 1) && !to_ws;
     const bool lead = (w.zsplit == 0);
     float* Cout = to_ws ? p.ws + (int64_t)w.zsplit * p.M * p.N : reinterpret_cast<float*>(C);
@@ -1251,6 +1266,26 @@ static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipSt
   return FCMF_OK;
 }
 // C (+)= sum_z ws[z]: the reduce pass of the workspace split-K (partials were just written: L2 / Infinity Cache hits)
+// C (+)= sum_z ws[z] for partial tiles stored in the FRAGMENT layout (the f32 epilogue above): ws[z][tile][wave][fj][fi][lane][4].
+// One thread sums the `ksplit` copies of one 16-byte piece (coalesced KiB reads per wave) and writes it to its (row, column).
+__global__ __launch_bounds__(256) void splitk_reduce_frag_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
+                                                                 int64_t ldc, int ksplit, int tiles, int tiles_n, int accumulate) {
+  const int64_t total = (int64_t)tiles * (GB * GB / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int tile = (int)(i >> 14), r = (int)(i & 16383);          // 16384 pieces of 4 floats per 256 x 256 tile
+    const int lane = r & 63, frag = (r >> 6) & 31, wave = r >> 11;
+    const int fj = frag >> 3, fi = frag & 7, wm = wave >> 2, wn = wave & 3;
+    const int row = (tile / tiles_n) * GB + wm * 128 + fi * 16 + (lane & 15);
+    const int col = (tile % tiles_n) * GB + wn * 64 + fj * 16 + (lane >> 4) * 4;
+    if (row >= M || col >= N) continue;
+    float* c = C + (int64_t)row * ldc + col;
+    f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int z = 0; z < ksplit; ++z) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ws + ((int64_t)z * tiles + tile) * (GB * GB) + (int64_t)r * 4));
+    *reinterpret_cast<f32x4*>(c) = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
                                                             int64_t ldc, int ksplit, int accumulate) {
   const int64_t total4 = (int64_t)M * N / 4;           // N % 8 == 0 on this path
@@ -1392,7 +1427,10 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
       dim3 grid(p.total_items < slots ? p.total_items : slots);
       p.ws = nullptr;
       p.nt_out = out_dtype == FCMF_BF16 && (int64_t)M * N * 2 >= cfg.nt_min_bytes;
-      if (p.ksplit > 1 && cfg.ws && cfg.ws_bytes >= (int64_t)p.ksplit * M * N * 4) p.ws = cfg.ws;
+      // (partial tiles are whole 256 x 256 fragment-layout tiles when the GEMM has neither bias nor column sums: size by tiles)
+      const bool frag_ws = !bias && !colsum;
+      const int64_t ws_need = frag_ws ? (int64_t)p.ksplit * tiles_l * GB * GB * 4 : (int64_t)p.ksplit * M * N * 4;
+      if (p.ksplit > 1 && out_dtype == FCMF_F32 && cfg.ws && cfg.ws_bytes >= ws_need) p.ws = cfg.ws;
       {
         static const char* const epi_names[] = {"NONE", "GELU", "TANH", "DGELU", "DTANH", "ADD"};
         if (kb == 64) snprintf(last_kernel, NAME, "gemm_bf16_tile%dk64_kernel<%s>", tm, epi_names[epilogue]);
@@ -1405,10 +1443,17 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
       else if (trans_a && !trans_b) rc = launch_bf16_tile<true, false>(p, out_dtype, grid, st, tm, kb);
       else rc = launch_bf16_tile<true, true>(p, out_dtype, grid, st, tm, kb);
       if (rc == FCMF_OK && p.ws) {
-        const int64_t total4 = (int64_t)M * N / 4;
-        const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, reinterpret_cast<float*>(C), M, N, ldc,
-                           p.ksplit, accumulate);
+        if (frag_ws) {
+          const int64_t total4 = (int64_t)tiles_l * (GB * GB / 4);
+          const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+          hipLaunchKernelGGL(splitk_reduce_frag_kernel, dim3(blocks), dim3(256), 0, st, p.ws, reinterpret_cast<float*>(C), M, N, ldc,
+                             p.ksplit, tiles_l, (N + GB - 1) / GB, accumulate);
+        } else {
+          const int64_t total4 = (int64_t)M * N / 4;
+          const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, reinterpret_cast<float*>(C), M, N, ldc,
+                             p.ksplit, accumulate);
+        }
         FCMF_CHECK_LAUNCH();
       }
       return rc;
