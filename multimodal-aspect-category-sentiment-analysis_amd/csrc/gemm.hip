@@ -390,9 +390,19 @@ __device__ __forceinline__ int swz_row64(int r) { return (r >> 1) & 7; }
 //           k of a row = the two 16-B chunks 2g, 2g+1; they are stored where the bf16 kernel's fragment reads look
 //           (physical chunk (g ^ swizzle) and the same + 4: conflict-free ds_read_b128 pairs), i.e. logical chunk
 //           c = 2g + h lives at physical chunk (g | h << 2) ^ swizzle.
-template <bool TR, int KB, bool FP8 = false>
+//  PAD (transposed tiles of the weight-gradient kernel): piece i holds k-rows r0(i) = 8 (i >> 2) + (i & 3) and r0(i) + 4 in natural
+//           column order and lies at LDS offset 1056 i (1 KiB + 32 B): the eight pieces a transposed fragment read touches start
+//           32 B apart modulo the 256-B bank row, so ds_read_b64_tr_b16 is conflict free WITHOUT an XOR on the column index --
+//           fragment f is a compile-time immediate offset (32 f) from one per-lane base (tools/lds_conflicts.py).
+template <bool TR, int KB, bool FP8 = false, bool PAD = false>
 __device__ __forceinline__ unsigned dma_voffset_t(int piece, int lane, int64_t ld, int x0, int xdim, const GemmParams* cv = nullptr) {
   const int q = piece * 64 + lane;             // 16-B slot inside the operand tile
+  if constexpr (PAD) {
+    static_assert(TR && KB == 32 && !FP8, "padded image: transposed 32-deep tiles");
+    const int kk = ((piece >> 2) << 3) + (piece & 3) + ((lane >> 5) << 2), c16 = lane & 31;
+    if (x0 + c16 * 8 >= xdim) return 0x80000000u;
+    return (unsigned)(((int64_t)kk * ld + x0 + c16 * 8) * 2);
+  }
   if (!TR && !FP8 && cv) {                     // implicit-GEMM convolution (A operand): row -> receptive-field origin
     const int row = KB == 32 ? q >> 2 : q >> 3, c = KB == 32 ? (q & 3) ^ swz_row(row) : (q & 7) ^ swz_row64(row);
     if (x0 + row >= xdim) return 0x80000000u;
@@ -442,6 +452,13 @@ __device__ __forceinline__ void store8f(float* q, const f32x2 (&v)[4]) {
 // epilogue (acc[i][j] * sa[i] * sb[j]).  Ring, DMA pieces, swizzled LDS image and fragment READ addresses are those of the
 // bf16 64-deep kernel; a k-tile is consumed in two M-halves (B fragments + A fragments 0-3, then A fragments 4-7) instead of
 // two K-halves, so the fragment registers stay at 64.
+// wait until at most N vector-memory operations are outstanding; the four registers of the awaited aux round are operands of the
+// statement, so no use of them is scheduled above it (cdna_hip_programming.md section 5.7, item 1, form (ii))
+template <int N>
+__device__ __forceinline__ void wait_vm(u32x4 (&r)[4]) {
+  static_assert(N >= 0 && N < 64, "vmcnt field");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 template <bool A_TR, bool B_TR, typename TC, int EPI, int MI, int KB, bool FP8 = false>
 __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
@@ -452,7 +469,10 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   constexpr int NW = 8;
   constexpr int TM = 32 * MI;                  // block tile rows
   constexpr int WM = 16 * MI;                  // rows per wave
-  constexpr int A_TILE_BYTES = GB * KB * 2;    // LDS bytes per operand tile (the 192-row A tile leaves a quarter unused)
+  // dW = dY^T X (both operands transposed, f32 output, no bf16 epilogue slices above the ring): padded transposed image
+  constexpr bool PAD_TR = A_TR && B_TR && sizeof(TC) == 4 && KB == 32;
+  constexpr int PIECE_STRIDE = PAD_TR ? 1056 : 1024;
+  constexpr int A_TILE_BYTES = PAD_TR ? 16 * PIECE_STRIDE : GB * KB * 2;    // LDS bytes per operand tile (the 192-row A tile leaves a quarter unused)
   constexpr int TSTAGE_BYTES = 2 * A_TILE_BYTES;
   constexpr int TNST = 4;                      // KB = 32: stages of the ring (A tile + B tile each)
   constexpr bool RING5 = KB == 64;             // KB = 64: five 32-KiB slots, one OPERAND tile each (see `base` below)
@@ -492,22 +512,24 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   const int row_base = KB == 32 ? rowl * 64 + ((g4 ^ swz_row(rowl)) << 4) : rowl * 128 + ((g4 ^ swz_row64(rowl)) << 4);
   const int trk = tr_key(8 * g4 + q4);
   const int tr_col = ((p4 >> 1) << 4) + ((p4 & 1) << 3);
-  const int a_lane = A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * WM * (2 * KB);
-  const int b_lane = B_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wn * 64 * (2 * KB);
+  // (padded image: k-row 8 g + q is the first half of piece 4 g + q, k-row + 4 its second half)
+  const int pad_lane = (4 * g4 + q4) * PIECE_STRIDE + p4 * 8;
+  const int a_lane = PAD_TR ? pad_lane + wm * 256 : A_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wm * WM * (2 * KB);
+  const int b_lane = PAD_TR ? pad_lane + wn * 128 : B_TR ? (8 * g4 + q4) * 512 + tr_col : row_base + wn * 64 * (2 * KB);
   auto frag_a = [&](const char* st, int f, int h) -> bf16x8 {     // f = 0..MI-1: 16-row fragment of this wave's rows
     if (!A_TR) return *reinterpret_cast<const bf16x8*>(st + (a_lane ^ (h << 6)) + f * (32 * KB));
-    const char* q = st + a_lane + (((wm * 8 + f) ^ trk) << 5) + h * 16384;
+    const char* q = PAD_TR ? st + a_lane + f * 32 : st + a_lane + (((wm * 8 + f) ^ trk) << 5) + h * 16384;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * 512));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + (PAD_TR ? 512 : 4 * 512)));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
   };
   auto frag_b = [&](const char* st, int f, int h) -> bf16x8 {     // f = 0..3
     if (!B_TR) return *reinterpret_cast<const bf16x8*>(st + (b_lane ^ (h << 6)) + f * (32 * KB));
-    const char* q = st + b_lane + (((wn * 4 + f) ^ trk) << 5) + h * 16384;
+    const char* q = PAD_TR ? st + b_lane + f * 32 : st + b_lane + (((wn * 4 + f) ^ trk) << 5) + h * 16384;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)q);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + 4 * 512));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(q + (PAD_TR ? 512 : 4 * 512)));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
@@ -541,9 +563,9 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   auto sources = [&](const Item& w) -> Src {
     Src r;
 #pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR, KB, FP8>(a_piece0 + j, lane, p.lda, w.i0, p.M, p.cv_C ? &p : nullptr);
+    for (int j = 0; j < A_PIECES; ++j) r.a[j] = dma_voffset_t<A_TR, KB, FP8, PAD_TR>(a_piece0 + j, lane, p.lda, w.i0, p.M, p.cv_C ? &p : nullptr);
 #pragma unroll
-    for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR, KB, FP8>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
+    for (int j = 0; j < B_PIECES; ++j) r.b[j] = dma_voffset_t<B_TR, KB, FP8, PAD_TR>(wave * B_PIECES + j, lane, p.ldb, w.j0, p.N);
     return r;
   };
   // DMA of k-tile t of item w: A tile to sa and / or B tile to sb (nullptr = skip)
@@ -554,7 +576,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
 #pragma unroll
       for (int j = 0; j < A_PIECES; ++j) {
         if (MI != 8 && j >= na_pieces) break;
-        char* d = sa + (a_piece0 + j) * 1024;
+        char* d = sa + (a_piece0 + j) * PIECE_STRIDE;
         if constexpr (ASM_DMA) {
           if (A_TR) dma16_asm0(wA, lds_addr_of(d), src.a[j] + ka);
           else      dma16_asm(wA, lds_addr_of(d), src.a[j], ka);
@@ -566,7 +588,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     if (sb) {
 #pragma unroll
       for (int j = 0; j < B_PIECES; ++j) {
-        char* d = sb + (wave * B_PIECES + j) * 1024;
+        char* d = sb + (wave * B_PIECES + j) * PIECE_STRIDE;
         if constexpr (ASM_DMA) {
           if (B_TR) dma16_asm0(wB, lds_addr_of(d), src.b[j] + kb);
           else      dma16_asm(wB, lds_addr_of(d), src.b[j], kb);
@@ -588,6 +610,13 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   bool pre = false;
 
   for (int item = slot; item < p.total_items; item += nblk) {
+  if constexpr (ASM_DMA && sizeof(TC) == 4) {
+    // The DMA of these kernels is invisible to hipcc (dma16_asm), but the previous item's output stores are not: left pending
+    // over the loop back-edge they make hipcc guard the first overwrite of their data registers with `s_waitcnt vmcnt(0)` -- and
+    // where that lands is scheduling luck (it has landed INSIDE the k-loop, draining the DMA ring once per k-tile).  A wait the
+    // compiler can see, here, where nothing of this item is in flight yet, empties its scoreboard for the whole main loop.
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0), expcnt / lgkmcnt untouched
+  }
   const Item w = decode(item);
   Src src = sources(w);
 #pragma unroll
@@ -696,14 +725,27 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     const int gj_r = j0 + wn * 64 + (lane & 7) * 8;
     aux_base = gj_r < p.N ? ((unsigned)(i0 + wm * WM + (lane >> 3)) * (unsigned)p.ldc + (unsigned)gj_r) * 2u : 0x80000000u;
   }
+  // 64-deep kernels: the aux rows are loaded from inline asm and awaited with HAND-COUNTED vmcnt.  hipcc does not trust the
+  // issue order between loads and stores on gfx9 (one vmcnt counter for both): with compiler-visible aux loads it closed every
+  // round of the epilogue with a vmcnt ladder down to 0, i.e. each round waited for the PREVIOUS round's output stores to be
+  // acknowledged by memory (~2 us each, three to four times per work item: the gelu' GEMM ran 720 TFLOP/s against 1025 of the
+  // plain kernel).  vmcnt retires in issue order on gfx950 (MI355X_MICROARCH.md, s_waitcnt paragraph), so "all but the N
+  // youngest" with N = the operations issued after the awaited loads is exact; a wait that names FEWER younger operations than
+  // really exist only waits longer, never too little (the optional bias loads and the next item's DMA prefetch are handled so).
+  constexpr bool ASM_AUX = HAS_AUX && RING5 && MI == 8;   // (192-row tile: its aux loads sit INSIDE the main loop; asm there cost 136 B of scratch)
+  [[maybe_unused]] const u32x4 wX = rsrc_words(p.aux, p.c_bytes);
   auto load_aux = [&](int rnd) __attribute__((always_inline)) {
     if constexpr (HAS_AUX) {
       const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, p.c_bytes, 0x00020000);
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
-        ax[rnd % NAX][it] = __builtin_amdgcn_raw_buffer_load_b128(rX, aux_base + (unsigned)(rnd * 32 + it * 8) * (unsigned)p.ldc * 2u, 0, 0);
+      for (int it = 0; it < 4; ++it) {
+        const unsigned off = aux_base + (unsigned)(rnd * 32 + it * 8) * (unsigned)p.ldc * 2u;
+        if constexpr (ASM_AUX) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ax[rnd % NAX][it]) : "v"(off), "s"(wX) : "memory");
+        else ax[rnd % NAX][it] = __builtin_amdgcn_raw_buffer_load_b128(rX, off, 0, 0);
+      }
     }
   };
+  // (waits: wait_vm<N> below names the four registers of the awaited round as operands, so no use of them is scheduled above it)
   // PING-PONG: waves w and w+4 share a SIMD.  Between barrier t and barrier t+1 group A (waves 0-3) feeds
   // (DMA, fragment reads of tile t) THEN multiplies tile t, while group B (waves 4-7) multiplies tile t-1
   // FIRST (fragments read in the previous interval) and feeds tile t afterwards: the SIMD's matrix pipe
@@ -861,6 +903,21 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       // would touch 16 lines per instruction) -> slice -> fragment layout, math, results -> slice -> rows -> C
 #pragma unroll
       for (int rnd = 0; rnd < MI / 2; ++rnd) {
+        if constexpr (ASM_AUX) {
+          // operations issued after the loads of round `rnd` (see load_aux): P = this wave's DMA pieces of the next item's first
+          // tiles (issued above, only if there is a next item), 4 loads per later aux round, 4 stores per finished round
+          constexpr int P = MI == 8 ? 8 : 7;
+          if constexpr (MI == 8) {            // ring of two: L0 L1 [P] | r0: L2, S0 | r1: L3, S1 | r2: S2 | r3
+            if (rnd == 0) { if (pre) wait_vm<4 + P>(ax[0]); else wait_vm<4>(ax[0]); }
+            else if (rnd == 1) { if (pre) wait_vm<8 + P>(ax[1 % NAX]); else wait_vm<8>(ax[1 % NAX]); }
+            else if (rnd == 2) wait_vm<12>(ax[2 % NAX]);
+            else wait_vm<8>(ax[3 % NAX]);
+          } else {                            // all three rounds loaded up front: L0 L1 L2 [P] | r0: S0 | r1: S1 | r2
+            if (rnd == 0) { if (pre) wait_vm<8 + P>(ax[0]); else wait_vm<8>(ax[0]); }
+            else if (rnd == 1) { if (pre) wait_vm<8 + P>(ax[1 % NAX]); else wait_vm<8>(ax[1 % NAX]); }
+            else { if (pre) wait_vm<8 + P>(ax[2 % NAX]); else wait_vm<8>(ax[2 % NAX]); }
+          }
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(row_addr(it)) = ax[rnd % NAX][it];
         if constexpr (!EARLY_AUX) { if (rnd + 2 < NRND) load_aux(rnd + 2); }
@@ -936,13 +993,18 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       // The workspace layout is ours to choose: the partial tile goes out in the FRAGMENT layout, straight from the accumulator
       // registers -- every store instruction is one contiguous KiB (64 lanes x 16 B), no LDS staging, no barrier.  The reduce pass
       // (splitk_reduce_frag_kernel) reads the partials back in the same order and only there maps (fragment, lane) to (row, column).
-      // (The row-layout path below staged 2 x 128 KiB through LDS between four barriers: ~35 us per work item of a 230 us dW.)
-      float* wsp = p.ws + ((int64_t)w.zsplit * p.tiles + (item - w.zsplit * p.tiles)) * (GB * GB) + (wave * 32 * 64 + lane) * 4;
+      // (The row-layout path below staged 2 x 128 KiB through LDS between four barriers.)  One VGPR of addressing: lane * 16;
+      // everything else of the address is wave-uniform (scalar offset of the buffer store).
+      int lane_w = lane;
+      asm volatile("" : "+v"(lane_w));            // (laundered: not hoisted above the main loop, where every VGPR is spoken for)
+      const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, 0x7FFFFFFF, 0x00020000);
+      const unsigned wbase = (unsigned)item * (unsigned)(GB * GB * 4) + (unsigned)wave * (32u * 1024u);
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj)
 #pragma unroll
         for (int fi = 0; fi < 8; ++fi)
-          __builtin_nontemporal_store(acc[fj][fi], reinterpret_cast<f32x4*>(wsp + (fj * 8 + fi) * 256));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[fj][fi]), rW, (unsigned)lane_w * 16u,
+                                                 wbase + (unsigned)(fj * 8 + fi) * 1024u, 0);
       base = (base + nkt) & (TNST - 1);
       continue;                                   // (barrier-free, like the bf16 epilogue: the next item's tiles 0-2 go to the three
                                                   //  stages every wave has finished reading; the fourth waits for ITS barrier 0)
@@ -1024,11 +1086,14 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         if (lane_e < LPR) red[wave * GB + lane_e * 8 + e] = t;
       }
       lds_barrier();
-      if (tid < GB) {
+      int tid_e = tid;
+      asm volatile("" : "+v"(tid_e));             // (laundered: the colsum address was hoisted to the kernel entry and SPILLED --
+                                                  //  one pending scratch store puts a vmcnt(0) into the main loop, see dma16_asm)
+      if (tid_e < GB) {
         float t = 0.f;
 #pragma unroll
-        for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * GB + tid];
-        if (j0 + tid < p.N) atomicAdd(p.colsum + j0 + tid, t);
+        for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * GB + tid_e];
+        if (j0 + tid_e < p.N) atomicAdd(p.colsum + j0 + tid_e, t);
       }
       lds_barrier();
     }
@@ -1281,7 +1346,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_frag_kernel(const float* __
     float* c = C + (int64_t)row * ldc + col;
     f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int z = 0; z < ksplit; ++z) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ws + ((int64_t)z * tiles + tile) * (GB * GB) + (int64_t)r * 4));
+    for (int z = 0; z < ksplit; ++z) s += *reinterpret_cast<const f32x4*>(ws + ((int64_t)z * tiles + tile) * (GB * GB) + (int64_t)r * 4);
     *reinterpret_cast<f32x4*>(c) = s;
   }
 }

@@ -92,3 +92,17 @@ if __name__ == "__main__":
     w64 = max(read_b128([off64(16 * f + (l & 15), 4 * h + (l >> 4)) for l in range(64)]) for f in range(16) for h in range(2))
     print("GEMM 128B-row tile (64-deep k-tiles): row read", w64, "way")
     assert w64 == 1
+    # ---- GEMM weight-gradient kernel (csrc/gemm.hip, PAD_TR): transposed [32 k][256 x] tile as 16 pieces of 1 KiB at a stride of
+    #      1056 B; piece i = k-rows 8 (i >> 2) + (i & 3) and + 4, natural column order.  Fragment f (16 columns = 32 B), lo / hi:
+    #      lane (g, q, p) reads 8 B at piece (4 g + q) + 512 hi + 32 f + 8 p  -- no XOR: f is an immediate offset
+    wp = 1
+    for f in range(16):
+        for hi in (0, 1):
+            a = []
+            for l in range(64):
+                g4, i16 = l >> 4, l & 15
+                q4, p = i16 >> 2, i16 & 3
+                a.append((4 * g4 + q4) * 1056 + 512 * hi + 32 * f + 8 * p)
+            wp = max(wp, read_tr_b64(a))
+    print("GEMM padded tr tile (1056-B pieces): tr read", wp, "way")
+    assert wp == 1
