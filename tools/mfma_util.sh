@@ -1,6 +1,6 @@
 #!/bin/bash
 # MFMA utilisation of the step's kernels as rocprofv3 counts it (run on the GPU box from the repo root):
-#   tools/mfma_util.sh -> gpurun_out/r02_mfma_util.txt
+#   TAG=r03 tools/mfma_util.sh -> gpurun_out/r03_mfma_util.txt
 # One --pmc pass (kernel-trace only) of bench.py with SQ_VALU_MFMA_BUSY_CYCLES (matrix-pipe busy cycles, summed over the
 # SIMDs) and GRBM_GUI_ACTIVE (GPU-active cycles at the clock the chip actually held, summed over the 8 XCDs:
 # MI355X_MICROARCH.md, DVFS give-back).  Per kernel:
@@ -9,7 +9,7 @@
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfu -o m -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/mfma_util.log 2>&1
-python3 - $OUT/mfu > $OUT/r02_mfma_util.txt <<'PY'
+python3 - $OUT/mfu > $OUT/${TAG:-r02}_mfma_util.txt <<'PY'
 import csv, sys, glob, collections
 d = sys.argv[1]
 cc = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
