@@ -1456,8 +1456,12 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
                          (out_dtype == FCMF_F32 || c_extent < (1ll << 31));
     // (weight gradients: the 256x256 kernel's row-wise f32 epilogue / 256-byte atomics beat the 128x128 kernel's
     // fragment-layout atomics from K = 1024 up -- 25 vs 97 us at 768x768x2048)
+    // f32 outputs WITHOUT accumulate (a fresh weight-gradient buffer: no zero fill needed) may still split K when the context
+    // owns a workspace: the reduce pass then writes the sum instead of adding it
+    const bool splittable = epilogue == FCMF_EPI_NONE && out_dtype == FCMF_F32 && !colsum &&
+                            (accumulate || (cfg.ws != nullptr && !bias));
     bool large = tile_ok && M >= 256 && N >= 256 &&
-                 ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (accumulate && K >= 512));
+                 ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (splittable && K >= 512));
     if (cfg.force_tile == 128) large = false;
     if (cfg.force_tile == 256 || cfg.force_tile == 192) large = tile_ok;
     if (large) {
@@ -1479,7 +1483,7 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
       const int kb = (cfg.kb64 && !trans_a && !trans_b && out_dtype == FCMF_BF16 && !accumulate && K % 64 == 0) ? 64 : 32;
       const int nk = (K + kb - 1) / kb;      // (shadows the 32-deep count above: the kernel counts k-tiles of ITS depth)
       int ksplit = 1;
-      if (accumulate && epilogue == FCMF_EPI_NONE && tiles_l < slots) {
+      if (splittable && tiles_l < slots) {
         ksplit = slots / tiles_l;
         const int min_kt = (nk * (kb / 32) >= 64 ? 8 : 6) / (kb / 32);   // >= 256 (192) k per work item: short contractions (K = 768 rows) split 4 ways
         if (ksplit > nk / min_kt) ksplit = nk / min_kt > 0 ? nk / min_kt : 1;
@@ -1496,6 +1500,9 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
       const bool frag_ws = !bias && !colsum;
       const int64_t ws_need = frag_ws ? (int64_t)p.ksplit * tiles_l * GB * GB * 4 : (int64_t)p.ksplit * M * N * 4;
       if (p.ksplit > 1 && out_dtype == FCMF_F32 && cfg.ws && cfg.ws_bytes >= ws_need) p.ws = cfg.ws;
+      if (p.ksplit > 1 && !accumulate && !p.ws) {       // (no workspace of that size: float atomics would need a zeroed C)
+        p.ksplit = 1; p.ktiles_per_split = nk; p.total_items = tiles_l;
+      }
       {
         static const char* const epi_names[] = {"NONE", "GELU", "TANH", "DGELU", "DTANH", "ADD"};
         if (kb == 64) snprintf(last_kernel, NAME, "gemm_bf16_tile%dk64_kernel<%s>", tm, epi_names[epilogue]);

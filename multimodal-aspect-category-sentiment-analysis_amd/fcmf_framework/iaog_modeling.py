@@ -117,8 +117,8 @@ class _SelfQuirkAttentionFn(torch.autograd.Function):
         _, kn = _pair_layouts(wk, wq, x2.dtype)
         dx = torch.empty((G * T, E), dtype=x2.dtype, device=x2.device)
         ops.gemm(dkq, kn(), dx, G * T, E, 2 * HD, 2 * HD, 2 * HD, E, 0, 0)                   # NT: both operands K-contiguous
-        dwl = torch.zeros((2 * HD, E), dtype=torch.float32, device=x2.device)
-        ops.gemm(dkq, x2, dwl, 2 * HD, E, G * T, 2 * HD, ops._ld(x2), E, 1, 1, acc=True)      # [2*n_head*d, E] = dkq^T x
+        dwl = torch.empty((2 * HD, E), dtype=torch.float32, device=x2.device)
+        ops.gemm(dkq, x2, dwl, 2 * HD, E, G * T, 2 * HD, ops._ld(x2), E, 1, 1)                # [2*n_head*d, E] = dkq^T x
         dw = dwl.view(2, nh, d, E).permute(0, 1, 3, 2)                                        # -> the parameters' [n_head, E, d]
         return dx.view(xshape), dw[0], dw[1], None, None
 
@@ -165,8 +165,8 @@ class _HoistedKeysFn(torch.autograd.Function):
         wt = ops.shadows.derived(wks[0], ("hoist_kn", e2.dtype, nb, wks[-1].data_ptr()), kn)
         de = torch.empty((G * T, E), dtype=e2.dtype, device=e2.device)
         ops.gemm(dk, wt, de, G * T, E, nb * HD, nb * HD, nb * HD, E, 0, 0)
-        dwl = torch.zeros((nb * HD, E), dtype=torch.float32, device=e2.device)
-        ops.gemm(dk, e2, dwl, nb * HD, E, G * T, nb * HD, ops._ld(e2), E, 1, 1, acc=True)
+        dwl = torch.empty((nb * HD, E), dtype=torch.float32, device=e2.device)
+        ops.gemm(dk, e2, dwl, nb * HD, E, G * T, nb * HD, ops._ld(e2), E, 1, 1)
         dw = dwl.view(nb, nh, d, E).permute(0, 1, 3, 2)
         return (de.view(eshape),) + tuple(dw[i] for i in range(nb))
 

@@ -343,7 +343,7 @@ def gemm_trace_end():
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI_NONE, acc=False, colsum=None):
     H.require_cuda(A, B, C)
-    ctx = H.gemm_ctx(workspace=acc)       # (weight-gradient GEMMs: the context owns the split-K scratch of this stream)
+    ctx = H.gemm_ctx(workspace=acc or C.dtype == torch.float32)   # (weight-gradient GEMMs: the context owns the split-K scratch of this stream)
     if _gemm_trace is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -536,8 +536,8 @@ class HeadLinearFn(torch.autograd.Function):
             gemm(dy2, kn(), dx, M, E, N, N, N, E, 0, 0)                      # NT: both operands K-contiguous
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dwl = torch.zeros((N, E), dtype=torch.float32, device=dy2.device)
-            gemm(dy2, x2, dwl, N, E, M, N, _ld(x2), E, 1, 1, acc=True)       # [n_head*d, E] = dy^T x
+            dwl = torch.empty((N, E), dtype=torch.float32, device=dy2.device)    # (fresh buffer: written, not accumulated into)
+            gemm(dy2, x2, dwl, N, E, M, N, _ld(x2), E, 1, 1)                 # [n_head*d, E] = dy^T x
             dw = dwl.view(nh, d, E).permute(0, 2, 1)                         # the parameter's [n_head, E, d] layout
         return dx, dw
 

@@ -179,6 +179,22 @@ def test_gemm_weight_grad_splitk(dev, dtype, Mtok):
     assert rel_err(dW, ref) < 1e-4 if dtype == torch.float32 else rel_err(dW, ref) < 2e-3
 
 
+@pytest.mark.parametrize("N,K,Mtok", [(768, 768, 768), (1536, 768, 960), (768, 3072, 8200), (300, 264, 4096)])
+def test_gemm_weight_grad_fresh_buffer_needs_no_zero_fill(dev, N, K, Mtok):
+    """dW = dY^T X into a FRESH float32 buffer (accumulate = 0): the persistent kernel still splits K through the context's
+    workspace -- partial tiles in the fragment layout, the reduce pass WRITES their sum -- so the buffer needs no zero fill
+    (the IAOG decoder's per-block weight gradients: 5 torch.zeros per block gone).  NaN-poisoned output, ragged tile edges."""
+    ops, H = _ops()
+    dY, X = _rand((Mtok, N), dev, torch.bfloat16, seed=1), _rand((Mtok, K), dev, torch.bfloat16, seed=2)
+    dW = torch.full((N, K), float("nan"), dtype=torch.float32, device=dev)
+    ops.gemm(dY, X, dW, N, K, Mtok, N, K, K, 1, 1)
+    ref = dY.float().cpu().t() @ X.float().cpu()
+    assert torch.isfinite(dW).all()
+    assert rel_err(dW, ref) < 2e-3
+    if N >= 256 and K >= 256:
+        assert H.last_gemm_kernel() == "gemm_bf16_tile256_kernel<1,1,f32,NONE>"
+
+
 @pytest.mark.parametrize("workspace", [True, False])
 def test_gemm_weight_grad_splitk_workspace_and_atomics(dev, workspace):
     """the persistent kernel's two split-K reductions (partial tiles in a registered workspace + reduce pass, float
