@@ -194,6 +194,15 @@ int fcmf_add_ln_bwd(const void* dy, const void* z, const float* gamma, const flo
                     const float* rstd, void* dz, void* dx, float* dgamma, float* dbeta, float* dxsum,
                     float* workspace, int rows, int H, float dropout_p, uint64_t seed, int dtype,
                     void* stream);
+/* fcmf_add_ln_fwd / fcmf_add_ln_bwd that ALSO emit the e4m3 copy (q8 [rows, H] bytes + qscale [rows], as fcmf_quant_fp8_rows
+ * would produce them from the stored values) of the tensor the next fp8 GEMM consumes: y for the forward, the gradient that
+ * flows into the producing Linear (dx with dropout, else dz) for the backward -- no separate quantisation pass over it. */
+int fcmf_add_ln_fwd_fp8(const void* x, const void* res, int64_t res_stride, const float* gamma, const float* beta, void* y,
+                        void* z, float* mean, float* rstd, int rows, int H, float eps, float dropout_p, uint64_t seed,
+                        int dtype, void* q8, float* qscale, void* stream);
+int fcmf_add_ln_bwd_fp8(const void* dy, const void* z, const float* gamma, const float* mean, const float* rstd, void* dz,
+                        void* dx, float* dgamma, float* dbeta, float* dxsum, float* workspace, int rows, int H,
+                        float dropout_p, uint64_t seed, int dtype, void* q8, float* qscale, void* stream);
 /* floats of scratch `workspace` must hold (per-workgroup partial column sums, reduced by a second
  * kernel without atomics); workspace == NULL falls back to float atomics. */
 int64_t fcmf_add_ln_bwd_workspace(int rows, int H);

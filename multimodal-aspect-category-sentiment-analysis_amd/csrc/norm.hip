@@ -12,7 +12,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          T* __restrict__ z, float* __restrict__ mean,
                                                          float* __restrict__ rstd, int rows, int H, float eps,
-                                                         float p, uint64_t seed) {
+                                                         float p, uint64_t seed, unsigned char* __restrict__ q8 = nullptr,
+                                                         float* __restrict__ qscale = nullptr) {
   const int lane = threadIdx.x & 63;
   const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   // grid-stride over rows with a one-row software pipeline: the next row's x (+res) is requested before the current
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
   }
   const float rs = rsqrtf(wave_sum(q) / (float)H + eps);
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int c = (i * 64 + lane) * 4;
@@ -83,6 +85,26 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
       o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
       o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
       Vec4<T>::store(y + (int64_t)row * H + c, o);
+      if (q8) {          // the values AS STORED (rounded to T): what fcmf_quant_fp8_rows would read back
+        o.x = to_f32<T>(from_f32<T>(o.x)); o.y = to_f32<T>(from_f32<T>(o.y)); o.z = to_f32<T>(from_f32<T>(o.z)); o.w = to_f32<T>(from_f32<T>(o.w));
+        v[i] = o;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+      }
+    }
+  }
+  if (q8) {              // e4m3 copy of the output row + its scale (the fp8 GEMM that consumes y: no separate quantisation pass)
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f, inv = 1.0f / sc;
+    if (lane == 0) qscale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        int w8 = 0;
+        w8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, w8, false);
+        w8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, w8, true);
+        *reinterpret_cast<int*>(q8 + (int64_t)row * H + c) = w8;
+      }
     }
   }
   }
@@ -96,7 +118,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                                                          T* __restrict__ dx, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, float* __restrict__ dxsum,
                                                          float* __restrict__ partial, int rows, int H, float p,
-                                                         uint64_t seed) {
+                                                         uint64_t seed, unsigned char* __restrict__ q8 = nullptr,
+                                                         float* __restrict__ qscale = nullptr) {
   __shared__ float4 red[2][3][NP][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
@@ -167,6 +190,29 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
         }
         // column sums of the gradient that flows into the producing Linear = its bias gradient
         ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
+        if (q8) {        // e4m3 copy of the gradient that flows into the producing Linear (dx with dropout, else dz), as stored
+          o.x = to_f32<T>(from_f32<T>(o.x)); o.y = to_f32<T>(from_f32<T>(o.y)); o.z = to_f32<T>(from_f32<T>(o.z)); o.w = to_f32<T>(from_f32<T>(o.w));
+          gy[i] = o;
+        }
+      }
+    }
+    if (q8) {
+      float amax = 0.f;
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        if ((i * 64 + lane) * 4 < H) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(gy[i].x), fabsf(gy[i].y)), fmaxf(fabsf(gy[i].z), fabsf(gy[i].w))));
+      amax = wave_max(amax);
+      const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f, inv = 1.0f / sc;
+      if (lane == 0) qscale[row] = sc;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < H) {
+          int w8 = 0;
+          w8 = __builtin_amdgcn_cvt_pk_fp8_f32(gy[i].x * inv, gy[i].y * inv, w8, false);
+          w8 = __builtin_amdgcn_cvt_pk_fp8_f32(gy[i].z * inv, gy[i].w * inv, w8, true);
+          *reinterpret_cast<int*>(q8 + (int64_t)row * H + c) = w8;
+        }
       }
     }
   }
@@ -402,9 +448,23 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const T* __restrict_
   } while (0)
 
 // ---- host ---------------------------------------------------------------------------------
+static int add_ln_fwd_impl(const void* x, const void* res, int64_t res_stride, const float* gamma, const float* beta, void* y,
+                           void* z, float* mean, float* rstd, int rows, int H, float eps, float dropout_p, uint64_t seed,
+                           int dtype, void* stream, void* q8, float* qscale);
 extern "C" int fcmf_add_ln_fwd(const void* x, const void* res, int64_t res_stride, const float* gamma,
                                const float* beta, void* y, void* z, float* mean, float* rstd, int rows, int H,
                                float eps, float dropout_p, uint64_t seed, int dtype, void* stream) {
+  return add_ln_fwd_impl(x, res, res_stride, gamma, beta, y, z, mean, rstd, rows, H, eps, dropout_p, seed, dtype, stream, nullptr, nullptr);
+}
+extern "C" int fcmf_add_ln_fwd_fp8(const void* x, const void* res, int64_t res_stride, const float* gamma,
+                                   const float* beta, void* y, void* z, float* mean, float* rstd, int rows, int H,
+                                   float eps, float dropout_p, uint64_t seed, int dtype, void* q8, float* qscale, void* stream) {
+  if (!q8 || !qscale) return FCMF_ERR_ARG;
+  return add_ln_fwd_impl(x, res, res_stride, gamma, beta, y, z, mean, rstd, rows, H, eps, dropout_p, seed, dtype, stream, q8, qscale);
+}
+static int add_ln_fwd_impl(const void* x, const void* res, int64_t res_stride, const float* gamma, const float* beta, void* y,
+                           void* z, float* mean, float* rstd, int rows, int H, float eps, float dropout_p, uint64_t seed,
+                           int dtype, void* stream, void* q8, float* qscale) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0 || H <= 0) return FCMF_ERR_ARG;
   if (H % 4 != 0 || H > LN_MAXP * 256 || (res && res_stride % 4 != 0)) return FCMF_ERR_UNSUPPORTED;
   if (rows == 0) return FCMF_OK;
@@ -413,7 +473,7 @@ extern "C" int fcmf_add_ln_fwd(const void* x, const void* res, int64_t res_strid
   dim3 grid(nblk > 2048 ? 2048 : nblk);      // 8 workgroups per CU; every wave walks its rows with the next one in flight
   if (dtype != FCMF_F32 && dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
 #define LAUNCH_(T, NP) hipLaunchKernelGGL((add_ln_fwd_kernel<T, NP>), grid, dim3(256), 0, st, (const T*)x, (const T*)res, \
-    res_stride, gamma, beta, (T*)y, (T*)z, mean, rstd, rows, H, eps, dropout_p, seed)
+    res_stride, gamma, beta, (T*)y, (T*)z, mean, rstd, rows, H, eps, dropout_p, seed, (unsigned char*)q8, qscale)
   LN_DISPATCH(dtype, H);
 #undef LAUNCH_
   FCMF_CHECK_LAUNCH();
@@ -427,9 +487,23 @@ static int ln_bwd_blocks(int rows) {
 
 extern "C" int64_t fcmf_add_ln_bwd_workspace(int rows, int H) { return (int64_t)ln_bwd_blocks(rows) * 3 * H; }
 
+static int add_ln_bwd_impl(const void* dy, const void* z, const float* gamma, const float* mean, const float* rstd, void* dz,
+                           void* dx, float* dgamma, float* dbeta, float* dxsum, float* workspace, int rows, int H,
+                           float dropout_p, uint64_t seed, int dtype, void* stream, void* q8, float* qscale);
 extern "C" int fcmf_add_ln_bwd(const void* dy, const void* z, const float* gamma, const float* mean, const float* rstd,
                                void* dz, void* dx, float* dgamma, float* dbeta, float* dxsum, float* workspace,
                                int rows, int H, float dropout_p, uint64_t seed, int dtype, void* stream) {
+  return add_ln_bwd_impl(dy, z, gamma, mean, rstd, dz, dx, dgamma, dbeta, dxsum, workspace, rows, H, dropout_p, seed, dtype, stream, nullptr, nullptr);
+}
+extern "C" int fcmf_add_ln_bwd_fp8(const void* dy, const void* z, const float* gamma, const float* mean, const float* rstd,
+                                   void* dz, void* dx, float* dgamma, float* dbeta, float* dxsum, float* workspace,
+                                   int rows, int H, float dropout_p, uint64_t seed, int dtype, void* q8, float* qscale, void* stream) {
+  if (!q8 || !qscale) return FCMF_ERR_ARG;
+  return add_ln_bwd_impl(dy, z, gamma, mean, rstd, dz, dx, dgamma, dbeta, dxsum, workspace, rows, H, dropout_p, seed, dtype, stream, q8, qscale);
+}
+static int add_ln_bwd_impl(const void* dy, const void* z, const float* gamma, const float* mean, const float* rstd, void* dz,
+                           void* dx, float* dgamma, float* dbeta, float* dxsum, float* workspace, int rows, int H,
+                           float dropout_p, uint64_t seed, int dtype, void* stream, void* q8, float* qscale) {
   if (!dy || !z || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || rows < 0 || H <= 0) return FCMF_ERR_ARG;
   if (H % 4 != 0 || H > LN_MAXP * 256) return FCMF_ERR_UNSUPPORTED;
   if (dropout_p > 0.f && !dx) return FCMF_ERR_ARG;
@@ -438,7 +512,8 @@ extern "C" int fcmf_add_ln_bwd(const void* dy, const void* z, const float* gamma
   const int blocks = ln_bwd_blocks(rows);
   if (dtype != FCMF_F32 && dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
 #define LAUNCH_(T, NP) hipLaunchKernelGGL((add_ln_bwd_kernel<T, NP>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)z, \
-    gamma, mean, rstd, (T*)dz, (T*)(dropout_p > 0.f ? dx : nullptr), dgamma, dbeta, dxsum, workspace, rows, H, dropout_p, seed)
+    gamma, mean, rstd, (T*)dz, (T*)(dropout_p > 0.f ? dx : nullptr), dgamma, dbeta, dxsum, workspace, rows, H, dropout_p, seed, \
+    (unsigned char*)q8, qscale)
   LN_DISPATCH(dtype, H);
 #undef LAUNCH_
   if (workspace)

@@ -52,6 +52,8 @@ SIGNATURES = {
                            _u64, _vp, _vp],
     "fcmf_add_ln_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _i, _vp],
     "fcmf_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _i, _vp],
+    "fcmf_add_ln_fwd_fp8": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _i, _vp, _vp, _vp],
+    "fcmf_add_ln_bwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _i, _vp, _vp, _vp],
     "fcmf_add_ln_bwd_workspace": [_i, _i],
     "fcmf_position_ids": [_vp, _vp, _i, _i, _i, _vp],
     "fcmf_embed_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _i, _vp],

@@ -177,25 +177,47 @@ def self_attention_bwd(qkv, mask, out, lse, dout, G, T, Hd, heads, p, seed, bias
 # --------------------------------------------------------------------------------------
 # shared tail: out-proj -> add+LN -> FFN -> add+LN
 # --------------------------------------------------------------------------------------
-def _ln_fwd(x, res, res_ld, g, b, eps, p, seed):
+def _want_q(rows, Hd, dtype):
+    """the fp8 mode quantises the LayerNorm output inside the LayerNorm kernel when an fp8 GEMM will consume it"""
+    return ops.fp8_enabled() and dtype == torch.bfloat16 and Hd % 128 == 0 and rows >= 256
+
+
+def _q_buffers(rows, Hd, device):
+    return torch.empty((rows, Hd), dtype=torch.uint8, device=device), torch.empty(rows, dtype=torch.float32, device=device)
+
+
+def _ln_fwd(x, res, res_ld, g, b, eps, p, seed, quant=False):
+    """-> y, z, mean, rstd, yq (= (e4m3 y, row scales) when `quant`, else None)"""
     rows, Hd = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     # z (the pre-LN sum) overwrites x in place
+    if quant:
+        q, sc = _q_buffers(rows, Hd, x.device)
+        H.check(H.lib().fcmf_add_ln_fwd_fp8(H.ptr(x), H.ptr(res), res_ld, H.ptr(g), H.ptr(b), H.ptr(y), H.ptr(x), H.ptr(mean),
+                                            H.ptr(rstd), rows, Hd, eps, p, seed, H.dt(x), H.ptr(q), H.ptr(sc), H.stream()), "fcmf_add_ln_fwd_fp8")
+        return y, x, mean, rstd, (q, sc)
     H.check(H.lib().fcmf_add_ln_fwd(H.ptr(x), H.ptr(res), res_ld, H.ptr(g), H.ptr(b), H.ptr(y), H.ptr(x), H.ptr(mean),
                                     H.ptr(rstd), rows, Hd, eps, p, seed, H.dt(x), H.stream()), "fcmf_add_ln_fwd")
-    return y, x, mean, rstd
+    return y, x, mean, rstd, None
 
 
-def _ln_bwd(dy, z, g, mean, rstd, p, seed, dg, db, dxsum):
+def _ln_bwd(dy, z, g, mean, rstd, p, seed, dg, db, dxsum, quant=False):
+    """-> dz, dx (the gradient into the producing Linear), dxq (its e4m3 copy + row scales when `quant`)"""
     dz = torch.empty_like(z)
     dx = torch.empty_like(z) if p > 0 else None
+    ws = ops.ln_workspace(z.shape[0], z.shape[1], z.device)
+    if quant:
+        q, sc = _q_buffers(z.shape[0], z.shape[1], z.device)
+        H.check(H.lib().fcmf_add_ln_bwd_fp8(H.ptr(dy), H.ptr(z), H.ptr(g), H.ptr(mean), H.ptr(rstd), H.ptr(dz), H.ptr(dx), H.ptr(dg),
+                                            H.ptr(db), H.ptr(dxsum), H.ptr(ws), z.shape[0], z.shape[1], p, seed, H.dt(z), H.ptr(q),
+                                            H.ptr(sc), H.stream()), "fcmf_add_ln_bwd_fp8")
+        return dz, (dx if dx is not None else dz), (q, sc)
     H.check(H.lib().fcmf_add_ln_bwd(H.ptr(dy), H.ptr(z), H.ptr(g), H.ptr(mean), H.ptr(rstd), H.ptr(dz), H.ptr(dx), H.ptr(dg),
-                                    H.ptr(db), H.ptr(dxsum), H.ptr(ops.ln_workspace(z.shape[0], z.shape[1], z.device)), z.shape[0],
-                                    z.shape[1], p, seed, H.dt(z), H.stream()),
+                                    H.ptr(db), H.ptr(dxsum), H.ptr(ws), z.shape[0], z.shape[1], p, seed, H.dt(z), H.stream()),
             "fcmf_add_ln_bwd")
-    return dz, (dx if dx is not None else dz)
+    return dz, (dx if dx is not None else dz), None
 
 
 def _post_fwd(c, res, res_ld, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2, eps, p, seeds):
@@ -206,13 +228,13 @@ def _post_fwd(c, res, res_ld, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2, eps, p, 
     co, c1, c2 = ops.as_compute(wo, dt), ops.as_compute(w1, dt), ops.as_compute(w2, dt)
     h = torch.empty((M, Hd), dtype=dt, device=c.device)
     ops.gemm_nt(c, wo, co, h, M, Hd, Hd, Hd, bias=bo.detach())
-    h1, z1, m1, r1 = _ln_fwd(h, res, res_ld, g1, be1, eps, p, seeds[0])
+    h1, z1, m1, r1, h1q = _ln_fwd(h, res, res_ld, g1, be1, eps, p, seeds[0], quant=_want_q(M, Hd, dt))
     u = torch.empty((M, I), dtype=dt, device=c.device)
     a = torch.empty((M, I), dtype=dt, device=c.device)
-    ops.gemm_nt(h1, w1, c1, a, M, I, Hd, Hd, bias=b1.detach(), aux=u, epi=H.EPI_GELU)
+    ops.gemm_nt(h1, w1, c1, a, M, I, Hd, Hd, bias=b1.detach(), aux=u, epi=H.EPI_GELU, xq=h1q)
     f = torch.empty((M, Hd), dtype=dt, device=c.device)
     ops.gemm_nt(a, w2, c2, f, M, Hd, I, I, bias=b2.detach())
-    y, z2, m2, r2 = _ln_fwd(f, h1, Hd, g2, be2, eps, p, seeds[1])
+    y, z2, m2, r2, _ = _ln_fwd(f, h1, Hd, g2, be2, eps, p, seeds[1])
     return y, (z1, m1, r1, h1, u, a, z2, m2, r2)
 
 
@@ -223,16 +245,16 @@ def _post_bwd(dy, c, saved, wo, w1, w2, g1, g2, p, seeds, G, side):
     M, Hd = c.shape
     I = w1.shape[0]
     co, c1, c2 = ops.as_compute(wo, dt), ops.as_compute(w1, dt), ops.as_compute(w2, dt)
-    dz2, df = _ln_bwd(dy, z2, g2, m2, r2, p, seeds[1], G["g2"], G["be2"], G["b2"])
+    dz2, df, dfq = _ln_bwd(dy, z2, g2, m2, r2, p, seeds[1], G["g2"], G["be2"], G["b2"], quant=_want_q(M, Hd, dt))
     du = torch.empty((M, I), dtype=dt, device=c.device)
-    ops.gemm_dx(df, w2, c2, du, M, I, Hd, aux=u, epi=H.EPI_DGELU, colsum=G["b1"])               # (df W2) * gelu'(u); db1
+    ops.gemm_dx(df, w2, c2, du, M, I, Hd, aux=u, epi=H.EPI_DGELU, colsum=G["b1"], dyq=dfq)      # (df W2) * gelu'(u); db1
     side.launch((df, a), df, a, G["w2"], Hd, I, M, Hd, I, I, 1, 1, acc=True)                   # dW2 = df^T a
     dh1 = torch.empty((M, Hd), dtype=dt, device=c.device)
     ops.gemm_dx(du, w1, c1, dh1, M, Hd, I, aux=dz2, epi=H.EPI_ADD)                             # du W1 + dz2 (residual)
     side.launch((du, h1), du, h1, G["w1"], I, Hd, M, I, Hd, Hd, 1, 1, acc=True)                # dW1 = du^T h1
-    dz1, dh = _ln_bwd(dh1, z1, g1, m1, r1, p, seeds[0], G["g1"], G["be1"], G["bo"])
+    dz1, dh, dhq = _ln_bwd(dh1, z1, g1, m1, r1, p, seeds[0], G["g1"], G["be1"], G["bo"], quant=_want_q(M, Hd, dt))
     dc = torch.empty((M, Hd), dtype=dt, device=c.device)
-    ops.gemm_dx(dh, wo, co, dc, M, Hd, Hd)
+    ops.gemm_dx(dh, wo, co, dc, M, Hd, Hd, dyq=dhq)
     side.launch((dh, c), dh, c, G["wo"], Hd, Hd, M, Hd, Hd, Hd, 1, 1, acc=True)
     return dc, dz1
 

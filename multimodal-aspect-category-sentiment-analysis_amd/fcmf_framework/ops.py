@@ -383,12 +383,12 @@ def gemm_fp8(xq, sx, wq, sw, C, M, N, K, bias=None, aux=None, epi=H.EPI_NONE, co
         _gemm_trace.append((H.lib().fcmf_gemm_ctx_last_kernel(ctx).decode(), 2.0 * M * N * K, e0, e1))
 
 
-def gemm_nt(x, weight, w_compute, y, M, N, K, ldx, bias=None, aux=None, epi=H.EPI_NONE, colsum=None, owner=None):
+def gemm_nt(x, weight, w_compute, y, M, N, K, ldx, bias=None, aux=None, epi=H.EPI_NONE, colsum=None, owner=None, xq=None):
     """y [M, N] = epilogue(x [M, K] W^T + bias), W [N, K]: the forward GEMM of nn.Linear.  `weight` = the float32 master (or a
     view of it; `owner` = its Parameter) when there is one: the fp8 mode then multiplies e4m3 copies (x quantised per row here,
     W per output row, cached); otherwise the bf16 / f32 kernel on `w_compute`."""
     if weight is not None and weight.dtype == torch.float32 and weight.dim() == 2 and _fp8_ok(M, N, K, N, x, y, aux):
-        xq, sx = quant_fp8_rows(x, M, K, ldx)
+        xq, sx = quant_fp8_rows(x, M, K, ldx) if xq is None else xq       # (xq: already quantised by the producing LayerNorm)
         wq, sw = shadows.get_fp8(weight, owner)
         gemm_fp8(xq, sx, wq, sw, y, M, N, K, bias=bias, aux=aux, epi=epi, colsum=colsum)
     else:
@@ -405,12 +405,12 @@ def _ld(x):
     return x.stride(0) if x.shape[0] > 1 else x.shape[1]
 
 
-def gemm_dx(dy, weight, w_compute, dx, M, K_in, N_out, aux=None, epi=H.EPI_NONE, colsum=None, owner=None):
+def gemm_dx(dy, weight, w_compute, dx, M, K_in, N_out, aux=None, epi=H.EPI_NONE, colsum=None, owner=None, dyq=None):
     """dx [M,K_in] = dy [M,N_out] @ W [N_out,K_in] (+ epilogue).  bf16 mode multiplies by the transposed bf16 copy of the
     float32 master `weight` (an NT GEMM); f32 mode, or a weight without a master, uses `w_compute` as it lies (NN)."""
     if (weight is not None and weight.dtype == torch.float32 and weight.dim() == 2 and dy.is_contiguous()
             and _fp8_ok(M, K_in, N_out, K_in, dy, dx, aux)):
-        dyq, sdy = quant_fp8_rows(dy, M, N_out, N_out)
+        dyq, sdy = quant_fp8_rows(dy, M, N_out, N_out) if dyq is None else dyq
         wq, sw = shadows.get_fp8_t(weight, owner)                    # [K_in, N_out] e4m3, scales per input row
         gemm_fp8(dyq, sdy, wq, sw, dx, M, K_in, N_out, aux=aux, epi=epi, colsum=colsum)
     elif dy.dtype == torch.bfloat16 and weight is not None and weight.dtype == torch.float32 and weight.dim() == 2:

@@ -51,3 +51,12 @@ def test_missing_library_is_loud(tmp_path, monkeypatch):
         raise AssertionError("expected HipLibraryError")
     except _hip.HipLibraryError as e:
         assert "no CPU/PyTorch fallback" in str(e)
+
+
+def test_docs_quote_the_real_entry_point_count():
+    """README.md and DESIGN.md state how many `extern "C"` entry points the header declares (round-2 verdict: they had drifted)"""
+    n = len(_declared())
+    for name in ("README.md", "DESIGN.md"):
+        text = open(os.path.join(ROOT, name)).read()
+        m = re.search(r"(\d+)\s+(?:`extern \"C\"`\s+)?entry points", text)
+        assert m and int(m.group(1)) == n, (name, m and m.group(1), n)

@@ -1061,3 +1061,32 @@ def test_fp8_linear_layers_forward_backward(dev):
         ops.set_fp8(False)
         ops.set_compute_dtype(torch.float32)
         ops.shadows.clear()
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_layernorm_emits_the_fp8_copy_its_consumer_needs(dev, p):
+    """fcmf_add_ln_fwd_fp8 / fcmf_add_ln_bwd_fp8: the e4m3 copy + row scales they emit are BIT-IDENTICAL to a separate
+    fcmf_quant_fp8_rows pass over the bf16 tensor they store (y; the gradient into the producing Linear), and every other
+    output is untouched -- the fp8 mode drops three quantisation passes per layer (ffn1 input, ffn2 / out-proj dX inputs)"""
+    ops, H = _ops()
+    from fcmf_framework import fused
+    rows, Hd = 1000, 1024
+    x = _rand((rows, Hd), dev, torch.bfloat16, 1.0, seed=1)
+    res = _rand((rows, Hd), dev, torch.bfloat16, 1.0, seed=2)
+    g, b = _rand((Hd,), dev, seed=3) + 1.0, _rand((Hd,), dev, seed=4)
+    y0, z0, m0, r0, none = fused._ln_fwd(x.clone(), res, Hd, g, b, 1e-5, p, 77)
+    y1, z1, m1, r1, (q, sc) = fused._ln_fwd(x.clone(), res, Hd, g, b, 1e-5, p, 77, quant=True)
+    assert none is None and torch.equal(y0, y1) and torch.equal(z0, z1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    q2, sc2 = ops.quant_fp8_rows(y1, rows, Hd, Hd)
+    assert torch.equal(q, q2) and torch.equal(sc, sc2)
+    dy = _rand((rows, Hd), dev, torch.bfloat16, 1.0, seed=5)
+    outs = []
+    for quant in (False, True):
+        dg, db, dxs = (torch.zeros(Hd, device=dev) for _ in range(3))
+        dz, dx, dq = fused._ln_bwd(dy, z1, g, m1, r1, p, 99, dg, db, dxs, quant=quant)
+        outs.append((dz, dx, dg, db, dxs, dq))
+    for a, b_ in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(a, b_)
+    q, sc = outs[1][5]
+    q2, sc2 = ops.quant_fp8_rows(outs[1][1], rows, Hd, Hd)
+    assert torch.equal(q, q2) and torch.equal(sc, sc2)
