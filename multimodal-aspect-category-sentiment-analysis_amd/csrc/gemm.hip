@@ -41,13 +41,11 @@ __device__ __forceinline__ unsigned conv_k_offset(const GemmParams& p, int kk) {
 
 // bf16-output epilogues use odd polynomials instead of erf/exp (no transcendental issue slots, no
 // selects): with xc = clamp(x, -X, X),
-//   Phi(x)   ~= 0.5 + xc * P5(xc^2), X = 3.5  (|err| <= 2.3e-4; gelu = x * Phi: |err| <= 8.2e-4, i.e. 2.3e-4 of |x|)
-//   gelu'(x) ~= 0.5 + xc * Q7(xc^2), X = 4.0  (|err| <= 5.2e-4)
-// both constrained to hit exactly 1 (0) at +X (-X), so the clamp alone saturates them; 4-8x below the bf16 resolution of
-// the values they produce (2^-9 relative).  Round 3 dropped two terms from each (round 2: 3.4e-5 / 2e-4): the polynomial IS
-// the cost of these epilogues -- ~7 us of VALU per 256 x 256 work item with the matrix pipes idle.  Evaluated two elements
-// at a time on the packed-f32 pipe (v_pk_fma_f32).  The fits are reproduced by the snippet in DESIGN.md (degrees 5 / 7,
-// X = 3.5 / 4.0).  The f32 parity path keeps the exact erff forms.
+//   Phi(x)   ~= 0.5 + xc * P7(xc^2), X = 4.0  (|err| <= 3.4e-5; gelu = x * Phi: |err| <= 1.4e-4)
+//   gelu'(x) ~= 0.5 + xc * Q9(xc^2), X = 4.5  (|err| <= 2e-4)
+// both constrained to hit exactly 1 (0) at +X (-X), so the clamp alone saturates them; all far below
+// bf16 resolution.  Evaluated two elements at a time on the packed-f32 pipe (v_pk_fma_f32).  The fits are
+// reproduced by the snippet in DESIGN.md.  The f32 parity path keeps the exact erff forms.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -62,19 +60,20 @@ __device__ __forceinline__ f32x4 clamp4(f32x4 x, float lim) {
                __builtin_amdgcn_fmed3f(x[2], -lim, lim), __builtin_amdgcn_fmed3f(x[3], -lim, lim)};
 }
 __device__ __forceinline__ f32x4 splat4(float c) { return f32x4{c, c, c, c}; }
-__device__ __forceinline__ f32x4 phi_poly4(f32x4 x) {      // Phi(x): 6 terms on [-3.5, 3.5]
-  const f32x4 xc = clamp4(x, 3.5f), t = xc * xc;
-  f32x4 p = splat4(-6.875718555e-07f);
-  p = p * t + splat4(3.440670116e-05f); p = p * t + splat4(-7.232382195e-04f); p = p * t + splat4(8.518474177e-03f);
-  p = p * t + splat4(-6.442032009e-02f); p = p * t + splat4(3.980805576e-01f);
+__device__ __forceinline__ f32x4 phi_poly4(f32x4 x) {      // Phi(x)
+  const f32x4 xc = clamp4(x, 4.0f), t = xc * xc;
+  f32x4 p = splat4(-1.304578543e-09f);
+  p = p * t + splat4(1.060087872e-07f); p = p * t + splat4(-3.746289010e-06f); p = p * t + splat4(7.662426288e-05f);
+  p = p * t + splat4(-1.023770734e-03f); p = p * t + splat4(9.590060957e-03f); p = p * t + splat4(-6.607606400e-02f);
+  p = p * t + splat4(3.988102128e-01f);
   return xc * p + splat4(0.5f);
 }
-__device__ __forceinline__ f32x4 dgelu_poly4(f32x4 x) {    // gelu'(x): 8 terms on [-4, 4]
-  const f32x4 xc = clamp4(x, 4.0f), t = xc * xc;
-  f32x4 p = splat4(-2.141259436e-08f);
-  p = p * t + splat4(1.522476282e-06f); p = p * t + splat4(-4.614765930e-05f); p = p * t + splat4(7.861559861e-04f);
-  p = p * t + splat4(-8.373686112e-03f); p = p * t + splat4(5.842847377e-02f); p = p * t + splat4(-2.662661970e-01f);
-  p = p * t + splat4(7.989855409e-01f);
+__device__ __forceinline__ f32x4 dgelu_poly4(f32x4 x) {    // gelu'(x)
+  const f32x4 xc = clamp4(x, 4.5f), t = xc * xc;
+  f32x4 p = splat4(-2.396099311e-11f);
+  p = p * t + splat4(2.702686828e-09f); p = p * t + splat4(-1.343048027e-07f); p = p * t + splat4(3.892256086e-06f);
+  p = p * t + splat4(-7.353425424e-05f); p = p * t + splat4(9.596712397e-04f); p = p * t + splat4(-8.909952021e-03f);
+  p = p * t + splat4(5.886488750e-02f); p = p * t + splat4(-2.652524630e-01f); p = p * t + splat4(7.977590902e-01f);
   return xc * p + splat4(0.5f);
 }
 __device__ __forceinline__ f32x2 phi_poly2(f32x2 x) { const f32x4 r = phi_poly4(f32x4{x[0], x[1], x[0], x[1]}); return f32x2{r[0], r[1]}; }

@@ -179,7 +179,7 @@ def test_gemm_weight_grad_splitk(dev, dtype, Mtok):
     assert rel_err(dW, ref) < 1e-4 if dtype == torch.float32 else rel_err(dW, ref) < 2e-3
 
 
-@pytest.mark.parametrize("N,K,Mtok", [(768, 768, 768), (1536, 768, 960), (768, 3072, 8200), (300, 264, 4096)])
+@pytest.mark.parametrize("N,K,Mtok", [(768, 768, 768), (1536, 768, 960), (768, 3072, 8200), (304, 264, 4096), (300, 264, 4096)])
 def test_gemm_weight_grad_fresh_buffer_needs_no_zero_fill(dev, N, K, Mtok):
     """dW = dY^T X into a FRESH float32 buffer (accumulate = 0): the persistent kernel still splits K through the context's
     workspace -- partial tiles in the fragment layout, the reduce pass WRITES their sum -- so the buffer needs no zero fill
@@ -191,7 +191,7 @@ def test_gemm_weight_grad_fresh_buffer_needs_no_zero_fill(dev, N, K, Mtok):
     ref = dY.float().cpu().t() @ X.float().cpu()
     assert torch.isfinite(dW).all()
     assert rel_err(dW, ref) < 2e-3
-    if N >= 256 and K >= 256:
+    if N >= 256 and K >= 256 and N % 8 == 0:     # (rows of 300 bf16 are not 16-byte aligned: the generic kernel, by design)
         assert H.last_gemm_kernel() == "gemm_bf16_tile256_kernel<1,1,f32,NONE>"
 
 
@@ -1085,8 +1085,10 @@ def test_layernorm_emits_the_fp8_copy_its_consumer_needs(dev, p):
         dg, db, dxs = (torch.zeros(Hd, device=dev) for _ in range(3))
         dz, dx, dq = fused._ln_bwd(dy, z1, g, m1, r1, p, 99, dg, db, dxs, quant=quant)
         outs.append((dz, dx, dg, db, dxs, dq))
-    for a, b_ in zip(outs[0][:5], outs[1][:5]):
+    for a, b_ in zip(outs[0][:2], outs[1][:2]):
         assert torch.equal(a, b_)
+    for a, b_ in zip(outs[0][2:5], outs[1][2:5]):      # (column sums: float atomics over 8 partial groups, order not fixed)
+        assert rel_err(a, b_) < 1e-5
     q, sc = outs[1][5]
     q2, sc2 = ops.quant_fp8_rows(outs[1][1], rows, Hd, Hd)
     assert torch.equal(q, q2) and torch.equal(sc, sc2)
