@@ -356,6 +356,15 @@ int fcmf_bn_apply(const void* x, const void* res, void* y, const float* scale, c
  * its owner; rows = n * H * W): the input of an implicit-GEMM 3x3 convolution, produced without a padding pass */
 int fcmf_bn_apply_pad(const void* x, const void* res, void* y_padded, const float* scale, const float* shift,
                       int64_t rows, int C, int64_t rows_per_group, int relu, int H, int W, int pad, int dtype, void* stream);
+/* fcmf_bn_finalize + fcmf_bn_apply / fcmf_bn_apply_pad in ONE launch: every workgroup derives the scale / shift of its channels
+ * from the totals in `sums` itself (sums == NULL: eval, running statistics), the first workgroup of a group leaves mean / rstd
+ * [groups, C] (both or neither) for the backward, workgroup 0 applies the `groups` running-statistics updates in group order.
+ * rows = groups * rows_per_group; pad = 0: y [rows, C] (may alias x); pad > 0: y the zero-bordered NHWC buffer (rows = n * H * W).
+ * FCMF_ERR_UNSUPPORTED unless C / (16 / sizeof(T)) is a power of two <= 256 and x / y / res are 16-byte aligned (the caller then
+ * takes the two separate entry points). */
+int fcmf_bn_finalize_apply(const void* x, const void* res, void* y, const double* sums, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* mean_out, float* rstd_out, int C, int groups,
+                           int64_t rows_per_group, float momentum, float eps, int relu, int H, int W, int pad, int dtype, void* stream);
 /* Implicit-GEMM convolution (no patch matrix): y[(n, oy, ox), co] = sum_{ky,kx,c} x[n, oy*stride + ky, ox*stride + kx, c] * w[co, (ky,kx,c)]
  * on the bf16 MFMA GEMM kernels -- the LDS-DMA of a k-tile reads tap (ky, kx) of every output pixel's receptive field straight
  * from the NHWC activation x [n, Hp, Wp, C], which INCLUDES the zero border where the convolution pads (Hp = H + 2 pad).
@@ -363,6 +372,30 @@ int fcmf_bn_apply_pad(const void* x, const void* res, void* y_padded, const floa
  * bf16, C a power of two >= 64, w [Cout, kh*kw*C] row-major in (ky, kx, c) order, y [n*Ho*Wo, Cout]. */
 int fcmf_conv_gemm(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int C, int Ho, int Wo,
                    int kh, int kw, int stride, int Cout, void* stream);
+/* Implicit-GEMM convolution for inputs with few channels -- the trunk's stem, conv1 = 7x7 / stride 2 / pad 3 on RGB crops
+ * (torchvision resnet152.conv1 driven by resnet_utils.py:13-24), whose patch matrix was 1.8 GB per 448 crops: x is NHWC bf16 with
+ * `pix` elements per pixel (a power of two: 4 = RGB0, written by fcmf_pack_rgb0) and its zero border; for every kernel row ky the
+ * contraction walks ONE contiguous run of `run` elements (a power of two >= 32, >= kw * pix: 32 = 8 pixels for kw = 7) starting at
+ * pixel (oy*stride + ky, ox*stride).  K = kh * run; w [Cout, kh * run] bf16 holds zeros where the run exceeds the kernel (kx >= kw,
+ * the padding channel).  stride * pix must be a multiple of 8 (16-byte DMA).  y [n*Ho*Wo, Cout] bf16. */
+int fcmf_conv_gemm_runs(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int pix, int run, int Ho,
+                        int Wo, int kh, int stride, int Cout, void* stream);
+/* crops in any layout (element strides of n, h, w, c; float32 / float64 / bf16; 3 channels) -> the interior of dst
+ * [N, H + 2 pad, Wp, 4] bf16, Wp >= W + 2 pad (channel 3 = 0; the border is NOT written: zero it once) */
+int fcmf_pack_rgb0(const void* src, int src_dtype, void* dst, int N, int H, int W, int64_t sn, int64_t sh, int64_t sw, int64_t sc,
+                   int pad, int Wp, void* stream);
+/* The 1x1 (plain GEMM: A [M, K] = the NHWC activation, W [N, K]) and implicit-GEMM convolutions with the statistics of the
+ * train-mode BatchNorm that follows EVERY convolution of the trunk (torchvision Bottleneck: conv -> bn, resnet_utils.py:13-24) as a
+ * by-product of the epilogue: stats [ceil(M / 128)][N][2] float32 <- (sum, sum of squares) of each block of 128 output rows per
+ * output channel, of the values as stored (bf16-rounded); plain stores, deterministic.  bf16 only.  FCMF_ERR_UNSUPPORTED where
+ * the shape does not run on the 256-row persistent kernel (M or N < 256, unaligned): run fcmf_gemm / fcmf_conv_gemm +
+ * fcmf_bn_stats instead.  fcmf_bn_stats_blocks: those blocks -> the per-group totals inside `sums` (a fcmf_bn_stats_workspace
+ * buffer) that fcmf_bn_finalize reads; rows_per_group must be a multiple of 128 (else FCMF_ERR_UNSUPPORTED). */
+int fcmf_gemm_colstats(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, float* stats, int M, int N, int K, int64_t lda,
+                       int64_t ldb, int64_t ldc, void* stream);
+int fcmf_conv_gemm_colstats(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, float* stats, int n, int Hp, int Wp, int C,
+                            int Ho, int Wo, int kh, int kw, int stride, int Cout, void* stream);
+int fcmf_bn_stats_blocks(const float* blockstats, double* sums, int64_t rows_per_group, int groups, int C, void* stream);
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC: [N,H,W,C] -> [N,(H-1)/2+1,(W-1)/2+1,C] */
 int fcmf_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 /* F.adaptive_avg_pool2d(x, [oh, ow]) of an NHWC activation, float32 output: layout 0 = [N, C, oh, ow] (what

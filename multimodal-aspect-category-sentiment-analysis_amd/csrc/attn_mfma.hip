@@ -500,6 +500,18 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
     }
   }
   const int nchunks = (nvalid + 31) >> 5;
+  // Dropout mask, shared between neighbouring lanes.  One hash decides the element PAIR (q, key & ~1), (q, key | 1); here the two
+  // elements sit in lanes l and l ^ 1 (key = .. + (lane & 15)), each holding rows q0 .. q0+3 -- computed per element, both lanes
+  // would evaluate the same four hashes (two 32-bit multiplies each, quarter rate: two thirds of this kernel's vector
+  // instructions).  Even lanes hash rows q0, q0+1, odd lanes q0+2, q0+3, and a quad-permute DPP move swaps them: two hashes per
+  // four elements.  Needs an even Tk (then every row starts on a pair boundary); the high word of the 64-bit pair index is
+  // wave-uniform unless the low word wraps inside this (sequence, head) -- checked, else the per-element form below.
+  const uint64_t pair_base = drop_base >> 1;
+  const uint32_t pb_lo = (uint32_t)pair_base, pb_hi = (uint32_t)(pair_base >> 32);
+  const bool share_hash = P.p > 0.f && (P.Tk & 1) == 0 && pb_lo <= 0xFFFF0000u;      // (pair offsets stay below 2^15: Tq, Tk <= 256)
+  const uint32_t hash_k0 = (uint32_t)P.seed ^ ((pb_hi << 7) | (pb_hi >> 25)), hash_s1 = (uint32_t)(P.seed >> 32);
+  const uint32_t drop_thr = dropout_threshold(P.p);
+  const int odd = lane & 1;
   f32x4 cV = f32x4{0.f, 0.f, 0.f, 0.f}, cK = f32x4{0.f, 0.f, 0.f, 0.f};   // column sums of dV / dK over the keys (this lane's keys)
   for (int c = 0; c < nchunks; ++c) {
     f32x4 aV[2], aK[2];
@@ -531,14 +543,26 @@ __device__ __forceinline__ void attn_mfma_bwd_body(const AttnMfmaParams& P) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
           f32x4 pdv, dsv;
+          float mult4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+          if (share_hash) {
+            const unsigned q0 = qt * AT + 32 * w + 16 * f + 4 * (lane >> 4);
+            const uint32_t o0 = pb_lo + __umul24(q0 + 2 * odd, (unsigned)P.Tk >> 1) + ((unsigned)key >> 1);
+            const uint32_t hA = fcmf_hash32_rounds(o0 ^ hash_k0, hash_s1);
+            const uint32_t hB = fcmf_hash32_rounds((o0 + ((unsigned)P.Tk >> 1)) ^ hash_k0, hash_s1);
+            const uint32_t nA = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hA, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]: lane ^ 1
+            const uint32_t nB = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hB, 0xB1, 0xf, 0xf, true);
+            const uint32_t hr[4] = {odd ? nA : hA, odd ? nB : hB, odd ? hA : nA, odd ? hB : nB};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mult4[r] = ((hr[r] >> (16 * odd)) & 0xFFFFu) >= drop_thr ? inv_keep : 0.f;   // (key & 1 == lane & 1)
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = qt * AT + 32 * w + 16 * f + 4 * (lane >> 4) + r;
-            float pr = 0.f, mult = 1.0f;
+            float pr = 0.f, mult = mult4[r];
             if (key < P.Tk && q < P.Tq) pr = __expf(sS[k4][f][r] * score_scale + mk - lse4[qt][f][r]);
             // element index ((g heads + h) Tq + q) Tk + key = a wave-uniform 64-bit base + a small 24-bit product: no
             // 64-bit vector multiply per element (integer multiplies are quarter rate; the kernel is VALU-bound)
-            if (P.p > 0.f) mult = dropout_mult(P.seed, drop_base + (__umul24((unsigned)q, (unsigned)P.Tk) + (unsigned)key), P.p, inv_keep);
+            if (P.p > 0.f && !share_hash) mult = dropout_mult(P.seed, drop_base + (__umul24((unsigned)q, (unsigned)P.Tk) + (unsigned)key), P.p, inv_keep);
             pdv[r] = pr * mult;
             dsv[r] = pr * (sP[k4][f][r] * mult - dl4[qt][f][r]);
           }

@@ -70,15 +70,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // it.  One 32-bit hash (the "lowbias32" integer finaliser: two 32-bit multiplies -- integer multiplies are
 // quarter rate on CDNA, so they are what a mask costs) decides TWO consecutive elements, 16 bits each: an
 // element is dropped when its 16 bits fall below p * 65536 (p is honoured to 1.5e-5).
-__device__ __forceinline__ uint32_t fcmf_hash32(uint64_t seed, uint64_t pair) {
-  const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
-  const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
-  uint32_t x = lo ^ s0 ^ ((hi << 7) | (hi >> 25));
+// (the two multiply rounds, given x = lo ^ seed_lo ^ rotl(hi, 7): kernels whose `hi` and seed are wave-uniform fold that part
+//  into one scalar and call this directly)
+__device__ __forceinline__ uint32_t fcmf_hash32_rounds(uint32_t x, uint32_t s1) {
   x ^= x >> 16; x *= 0x7feb352du;
   x ^= s1;
   x ^= x >> 15; x *= 0x846ca68bu;
   x ^= x >> 16;
   return x;
+}
+__device__ __forceinline__ uint32_t fcmf_hash32(uint64_t seed, uint64_t pair) {
+  const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
+  return fcmf_hash32_rounds(lo ^ s0 ^ ((hi << 7) | (hi >> 25)), s1);
 }
 __device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 // returns the multiplier applied to the element: 0 (dropped) or 1/(1-p) (kept)

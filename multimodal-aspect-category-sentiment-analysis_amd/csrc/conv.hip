@@ -71,6 +71,28 @@ __global__ __launch_bounds__(256) void im2col_nhwc8_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// RGB crops (any layout: element strides sn, sh, sw, sc; float32 / float64 / bf16) -> the zero-bordered NHWC input of
+// fcmf_conv_gemm_runs: dst [N, H + 2 pad, Wp >= W + 2 pad, 4] in bf16, channel 3 = 0; only the interior is written (the border
+// was zeroed once by the buffer's owner).  One thread per pixel, 8-byte stores; reads are coalesced along w.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ __launch_bounds__(256) void pack_rgb0_kernel(const TS* __restrict__ src, bf16_t* __restrict__ dst, int N, int H, int W,
+                                                        int64_t sn, int64_t sh, int64_t sw, int64_t sc, int pad, int Wp) {
+  const int64_t total = (int64_t)N * H * W;
+  const int Hp = H + 2 * pad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int w = (int)(idx % W);
+    const int64_t t = idx / W;
+    const int h = (int)(t % H);
+    const int64_t n = t / H;
+    const TS* q = src + n * sn + h * sh + w * sw;
+    bf16x4 o;
+    o[0] = (bf16_t)(float)q[0]; o[1] = (bf16_t)(float)q[sc]; o[2] = (bf16_t)(float)q[2 * sc]; o[3] = (bf16_t)0.f;
+    *reinterpret_cast<bf16x4*>(dst + ((n * Hp + h + pad) * Wp + w + pad) * 4) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // grouped batch statistics.  grid (channel slabs of 256, row chunks, groups); a thread owns 4 adjacent channels and
 // every (256 / vecs-per-row)-th row of its chunk; waves are reduced through LDS; one double atomic per channel and
 // workgroup.  sums [G, C, 2] (sum, sum of squares) must be zero on entry.
@@ -142,6 +164,35 @@ __global__ __launch_bounds__(1024) void bn_reduce_chunks_kernel(const double* __
   }
 }
 
+// the same reduction over the float32 block statistics a colstats GEMM left behind (fcmf_gemm_colstats: [row block of 128][C][2]):
+// group g = blocks g * nblocks .. (g + 1) * nblocks - 1.  Summed in double, in a fixed order.
+__global__ __launch_bounds__(1024) void bn_reduce_blocks_kernel(const float* __restrict__ stats, double* __restrict__ tot, int C,
+                                                                int nblocks) {
+  __shared__ double red[2][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, g = blockIdx.y;
+  double s = 0, q = 0;
+  if (c < C) {
+    const float2* p = reinterpret_cast<const float2*>(stats) + ((int64_t)g * nblocks + w) * C + c;
+    int k = w;
+    for (; k + 48 < nblocks; k += 64) {       // four block rows in flight per lane
+      const float2 a = p[0], b = p[(int64_t)16 * C], d = p[(int64_t)32 * C], e = p[(int64_t)48 * C];
+      s += ((double)a.x + (double)b.x) + ((double)d.x + (double)e.x);
+      q += ((double)a.y + (double)b.y) + ((double)d.y + (double)e.y);
+      p += (int64_t)64 * C;
+    }
+    for (; k < nblocks; k += 16) { const float2 a = p[0]; s += a.x; q += a.y; p += (int64_t)16 * C; }
+  }
+  red[0][w][lane] = s;
+  red[1][w][lane] = q;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    for (int k = 1; k < 16; ++k) { s += red[0][k][lane]; q += red[1][k][lane]; }
+    tot[((int64_t)g * C + c) * 2] = s;
+    tot[((int64_t)g * C + c) * 2 + 1] = q;
+  }
+}
+
 // one thread per channel.  training: group g's batch mean / biased variance -> scale/shift[g]; running statistics
 // take one EMA update per group IN GROUP ORDER with the unbiased variance (nn.BatchNorm2d, one reference call per
 // group).  eval (sums == NULL): scale/shift[0] from the running statistics.
@@ -150,7 +201,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                           float* __restrict__ rvar, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out, int C, int G, double count,
-                                                          float momentum, float eps) {
+                                                          double inv_count, float momentum, float eps) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const float w = gamma[c], b = beta[c];
@@ -164,8 +215,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   float rm = rmean[c], rv = rvar[c];
   for (int g = 0; g < G; ++g) {
     const double s = sums[((int64_t)g * C + c) * 2], q = sums[((int64_t)g * C + c) * 2 + 1];      // totals
-    const double mean = s / count;
-    double var = q / count - mean * mean;
+    const double mean = s * inv_count;
+    double var = q * inv_count - mean * mean;
     var = var > 0 ? var : 0;
     const float rs = 1.0f / sqrtf((float)var + eps), sc = w * rs;
     scale[(int64_t)g * C + c] = sc;
@@ -207,6 +258,115 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     Vec4<T>::store(y + orow * C + c, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fcmf_bn_finalize + fcmf_bn_apply in one launch (the trunk's forward ran 155 BatchNorms per pass as statistics / reduce /
+// finalize / apply: the one-thread-per-channel finalize kernel was 5 us of launch latency each).  A workgroup streams a
+// contiguous row range of ONE group; a thread owns E = 16 / sizeof(T) fixed channels (C / E lanes per row, a power of two
+// <= 256, so a lane's channels do not change as it strides the rows): it derives their scale / shift from the group's totals
+// itself (same arithmetic as bn_finalize_kernel), then moves 16 B per access, four rows in flight.  The first workgroup of
+// every group leaves mean / rstd for the backward; workgroup 0 applies the `groups` running-statistics updates in group order.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                                const double* __restrict__ tot, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ rmean,
+                                                                float* __restrict__ rvar, float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out, int C, int logCE, int64_t rows_per_group,
+                                                                int groups, int rows_per_block, int blocks_per_group, double count,
+                                                                double inv_count, float momentum, float eps, int relu, int H, int W, int pad) {
+  constexpr int E = 16 / (int)sizeof(T);
+  typedef T VecT __attribute__((ext_vector_type(E)));
+  const int tid = threadIdx.x, CE = 1 << logCE;
+  const int g = blockIdx.x / blocks_per_group, bg = blockIdx.x - g * blocks_per_group;
+  const int c0 = (tid & (CE - 1)) * E;
+  // the workgroups of a group sweep it TOGETHER (vector i of the group belongs to workgroup (i / 256) % blocks_per_group): the
+  // chip works inside one moving window per group instead of thousands of distant streams
+  const int64_t r0 = (int64_t)g * rows_per_group;
+  const int64_t n = rows_per_group << logCE;           // 16-byte vectors of the group: contiguous in x / res
+  const int64_t S = (int64_t)blocks_per_group * 256;
+  const VecT* xv = reinterpret_cast<const VecT*>(x + r0 * C);
+  const VecT* rv4 = res ? reinterpret_cast<const VecT*>(res + r0 * C) : nullptr;
+  // software pipeline, four vectors per thread and stage; the FIRST stage is requested before the scale / shift derivation
+  // below, whose dependent chain (totals -> double arithmetic -> rsqrt) would otherwise sit in front of every workgroup's
+  // first memory round trip (the tensors of layer3 are 4096 vectors per workgroup: the chain was a fifth of their time)
+  VecT na[4], nb[4];
+  auto load_stage = [&](int64_t i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k * S < n) { na[k] = xv[i + k * S]; if (rv4) nb[k] = rv4[i + k * S]; }
+  };
+  int64_t i = (int64_t)bg * 256 + tid;
+  load_stage(i);
+
+  float sc[E], sh[E];
+  auto stats_of = [&](int gg, int c, float& mean, float& rs, double& var) {
+    const double s = tot[((int64_t)gg * C + c) * 2], q = tot[((int64_t)gg * C + c) * 2 + 1];
+    const double m = s * inv_count;        // (as bn_finalize_kernel: a double division per channel and thread would cost more than the rows)
+    var = q * inv_count - m * m;
+    var = var > 0 ? var : 0;
+    mean = (float)m;
+    rs = 1.0f / sqrtf((float)var + eps);
+  };
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int c = c0 + e;
+    float mean, rs;
+    double var;
+    if (tot) stats_of(g, c, mean, rs, var);
+    else { mean = rmean[c]; rs = 1.0f / sqrtf(rvar[c] + eps); }
+    sc[e] = gamma[c] * rs;
+    sh[e] = beta[c] - mean * sc[e];
+    if (bg == 0 && tid < CE && mean_out) { mean_out[(int64_t)g * C + c] = mean; rstd_out[(int64_t)g * C + c] = rs; }
+  }
+  if (tot && blockIdx.x == 0 && tid < CE) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int c = c0 + e;
+      float rm = rmean[c], rv = rvar[c];
+      for (int gg = 0; gg < groups; ++gg) {
+        float mean, rs;
+        double var;
+        stats_of(gg, c, mean, rs, var);
+        const double unbiased = count > 1 ? var * count / (count - 1) : var;
+        rm = (1.f - momentum) * rm + momentum * mean;
+        rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+      }
+      rmean[c] = rm;
+      rvar[c] = rv;
+    }
+  }
+  auto out_ptr = [&](int64_t j) -> VecT* {
+    int64_t row = r0 + (j >> logCE);
+    if (pad > 0) {
+      const unsigned rw = (unsigned)row;               // (rows < 2^31: checked by the host)
+      const unsigned t = rw / (unsigned)W, w = rw - t * (unsigned)W;
+      const unsigned nimg = t / (unsigned)H, h = t - nimg * (unsigned)H;
+      row = ((int64_t)nimg * (H + 2 * pad) + h + pad) * (W + 2 * pad) + w + pad;
+    }
+    return reinterpret_cast<VecT*>(y + row * C + c0);
+  };
+  auto norm = [&](VecT v, VecT r, bool has_r) -> VecT {
+    VecT o;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float f = (float)v[e] * sc[e] + sh[e];
+      if (has_r) f += (float)r[e];
+      if (relu) f = fmaxf(f, 0.f);
+      o[e] = (T)f;
+    }
+    return o;
+  };
+  for (; i < n; i += 4 * S) {
+    VecT ca[4], cb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ca[k] = na[k]; cb[k] = nb[k]; }
+    if (i + 4 * S < n) load_stage(i + 4 * S);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k * S < n) *out_ptr(i + k * S) = norm(ca[k], cb[k], rv4 != nullptr);
   }
 }
 
@@ -485,6 +645,19 @@ extern "C" int fcmf_conv_im2col(const void* src, int src_dtype, void* dst, int d
   return FCMF_OK;
 }
 
+extern "C" int fcmf_pack_rgb0(const void* src, int src_dtype, void* dst, int N, int H, int W, int64_t sn, int64_t sh, int64_t sw,
+                              int64_t sc, int pad, int Wp, void* stream) {
+  if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || pad < 0 || Wp < W + 2 * pad) return FCMF_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for((int64_t)N * H * W);
+  if (src_dtype == FCMF_F32) hipLaunchKernelGGL((pack_rgb0_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, N, H, W, sn, sh, sw, sc, pad, Wp);
+  else if (src_dtype == FCMF_F64) hipLaunchKernelGGL((pack_rgb0_kernel<double>), dim3(g), dim3(256), 0, st, (const double*)src, (bf16_t*)dst, N, H, W, sn, sh, sw, sc, pad, Wp);
+  else if (src_dtype == FCMF_BF16) hipLaunchKernelGGL((pack_rgb0_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, H, W, sn, sh, sw, sc, pad, Wp);
+  else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
 // row chunking of the statistics kernels: enough workgroups to fill the chip, at most 4096 rows per workgroup (a thread's
 // float partial sum covers <= 1024 values; everything above is added in double).  Returns the number of chunks per group (= partial rows per (group, channel) in `sums`).
 static int bn_chunking(int64_t rows_per_group, int groups, int C, int* chunk_rows) {
@@ -526,6 +699,17 @@ extern "C" int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group
   return FCMF_OK;
 }
 
+// block statistics of a colstats GEMM -> the per-group totals, where fcmf_bn_finalize expects them inside `sums` (a workspace of
+// fcmf_bn_stats_workspace(rows_per_group, groups, C) doubles, as for fcmf_bn_stats).  Groups are whole multiples of 128 rows.
+extern "C" int fcmf_bn_stats_blocks(const float* blockstats, double* sums, int64_t rows_per_group, int groups, int C, void* stream) {
+  if (!blockstats || !sums || rows_per_group <= 0 || groups <= 0 || !bn_shape_ok(C)) return FCMF_ERR_ARG;
+  if (rows_per_group % 128 != 0 || groups > 65535) return FCMF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_reduce_blocks_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
+                     blockstats, bn_totals(sums, rows_per_group, groups, C), C, (int)(rows_per_group / 128));
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
 extern "C" int fcmf_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
                                 int groups, int64_t count, float momentum, float eps, void* stream) {
@@ -534,7 +718,49 @@ extern "C" int fcmf_bn_finalize(const double* sums, const float* gamma, const fl
   const double* tot = sums ? bn_totals(const_cast<double*>(sums), count, groups, C) : nullptr;   // where fcmf_bn_stats left them
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tot,
                      gamma, beta, running_mean, running_var, scale, shift, mean_out, rstd_out, C, groups, (double)count,
-                     momentum, eps);
+                     count > 0 ? 1.0 / (double)count : 0.0, momentum, eps);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+// fcmf_bn_finalize + fcmf_bn_apply(_pad) in ONE launch (see bn_finalize_apply_kernel).  sums as for fcmf_bn_finalize (NULL = eval:
+// running statistics); groups * rows_per_group rows; pad = 0: y [rows, C] (may alias x), else y the zero-bordered NHWC buffer of
+// fcmf_bn_apply_pad.  FCMF_ERR_UNSUPPORTED unless C / (16 / sizeof(T)) is a power of two <= 256 and the tensors are 16-byte
+// aligned: the caller then uses the two separate entry points.
+extern "C" int fcmf_bn_finalize_apply(const void* x, const void* res, void* y, const double* sums, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float* mean_out, float* rstd_out, int C, int groups,
+                                      int64_t rows_per_group, float momentum, float eps, int relu, int H, int W, int pad, int dtype,
+                                      void* stream) {
+  if (!x || !y || !gamma || !beta || !running_mean || !running_var || C <= 0 || groups <= 0 || rows_per_group <= 0) return FCMF_ERR_ARG;
+  if ((mean_out == nullptr) != (rstd_out == nullptr) || pad < 0) return FCMF_ERR_ARG;
+  if (pad > 0 && (H <= 0 || W <= 0 || rows_per_group * groups % ((int64_t)H * W) != 0)) return FCMF_ERR_ARG;
+  if (dtype != FCMF_F32 && dtype != FCMF_BF16) return FCMF_ERR_UNSUPPORTED;
+  const int E = dtype == FCMF_F32 ? 4 : 8;
+  if (C % E != 0 || groups > 65535) return FCMF_ERR_UNSUPPORTED;
+  const int CE = C / E;
+  int logCE = 0;
+  while ((1 << logCE) < CE) ++logCE;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if ((1 << logCE) != CE || CE > 256 || !al16(x) || !al16(y) || (res && !al16(res))) return FCMF_ERR_UNSUPPORTED;
+  const double* tot = sums ? bn_totals(const_cast<double*>(sums), rows_per_group, groups, C) : nullptr;
+  // >= 4096 vectors per workgroup (16 per thread) unless that leaves the chip empty; at most ~4096 workgroups
+  const int64_t vec_per_group = rows_per_group * CE;
+  int64_t bpg = (vec_per_group + 4095) / 4096;
+  const int64_t cap = (4096 + groups - 1) / groups;
+  if (bpg > cap) bpg = cap;
+  if (bpg < 1) bpg = 1;
+  const int64_t rpb = 0;      // (kept in the kernel's signature; the sweep is interleaved, not by row ranges)
+  if (rows_per_group * groups >= (1ll << 31)) return FCMF_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(bpg * groups));
+  if (dtype == FCMF_F32)
+    hipLaunchKernelGGL((bn_finalize_apply_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (const float*)res, (float*)y, tot, gamma, beta,
+                       running_mean, running_var, mean_out, rstd_out, C, logCE, rows_per_group, groups, (int)rpb, (int)bpg,
+                       (double)rows_per_group, 1.0 / (double)rows_per_group, momentum, eps, relu, H, W, pad);
+  else
+    hipLaunchKernelGGL((bn_finalize_apply_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, tot, gamma,
+                       beta, running_mean, running_var, mean_out, rstd_out, C, logCE, rows_per_group, groups, (int)rpb, (int)bpg,
+                       (double)rows_per_group, 1.0 / (double)rows_per_group, momentum, eps, relu, H, W, pad);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }

@@ -25,18 +25,24 @@ struct GemmParams {
   // implicit-GEMM convolution (cv_C > 0): A is an NHWC activation [n, Hp, Wp, C] (zero border included where the convolution
   // pads), row m = output pixel (n, oy, ox), k = (ky, kx, c).  C is a power of two and a multiple of the k-tile depth.
   int cv_C, cv_logC, cv_Hp, cv_Wp, cv_Ho, cv_Wo, cv_kw, cv_inv_kw, cv_stride;
+  // optional (256-row bf16 kernels, no aux operand): colstats[b][n] = (sum, sum of squares) over the rows 128 b .. 128 b + 127 of
+  // column n of C as stored -- the BatchNorm statistics of a convolution's output without a pass over it (plain stores)
+  float* colstats;
+  // log2 of the element distance between neighbouring pixels of the convolution's input (= cv_logC for an NHWC activation
+  // whose k-tiles walk the channels of one tap; smaller for fcmf_conv_gemm_runs, whose "tap" is a run of several whole pixels)
+  int cv_logP;
 };
 
 // element offset of the receptive-field origin of output row `row` in the (padded) input
 __device__ __forceinline__ int64_t conv_row_base(const GemmParams& p, int row) {
   const int hw = p.cv_Ho * p.cv_Wo, n = row / hw, rem = row - n * hw, oy = rem / p.cv_Wo, ox = rem - oy * p.cv_Wo;
-  return (((int64_t)n * p.cv_Hp + oy * p.cv_stride) * p.cv_Wp + ox * p.cv_stride) << p.cv_logC;
+  return (((int64_t)n * p.cv_Hp + oy * p.cv_stride) * p.cv_Wp + ox * p.cv_stride) << p.cv_logP;
 }
 // byte offset (wave-uniform: the DMA's scalar offset) of the k-tile that starts at contraction index kk: tap (ky, kx), channel c0
 __device__ __forceinline__ unsigned conv_k_offset(const GemmParams& p, int kk) {
   const int tap = kk >> p.cv_logC, c0 = kk & (p.cv_C - 1);
   const int ky = (tap * p.cv_inv_kw) >> 16, kx = tap - ky * p.cv_kw;
-  return (unsigned)((((ky * p.cv_Wp + kx) << p.cv_logC) + c0) * 2);
+  return (unsigned)((((ky * p.cv_Wp + kx) << p.cv_logP) + c0) * 2);
 }
 
 // bf16-output epilogues use odd polynomials instead of erf/exp (no transcendental issue slots, no
@@ -878,6 +884,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       return r;
     };
     float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // column sums of the values as stored (bf16-rounded)
+    [[maybe_unused]] float csq[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // ... and of their squares (colstats)
     // rows of the slice -> global (16 B per lane), optionally summing the columns
     auto store_round = [&](int rnd, const __amdgpu_buffer_rsrc_t& rD, bool sums) __attribute__((always_inline)) {
       bf16x8 x[4];
@@ -893,7 +900,11 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
           const int gi = i0 + wm * WM + rnd * 32 + it * 8 + rrow;
           if (gi < p.M) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) csum[e] += (float)x[it][e];
+            for (int e = 0; e < 8; ++e) {
+              const float xv = (float)x[it][e];
+              csum[e] += xv;
+              if constexpr (MI == 8 && !HAS_AUX) csq[e] = __builtin_fmaf(xv, xv, csq[e]);   // (colstats; the aux epilogues have no register to spare)
+            }
           }
         }
       }
@@ -971,7 +982,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
       if constexpr (EPI == FCMF_EPI_GELU) {
         if (two_pass) write_out(o0, __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, p.c_bytes, 0x00020000), false);
       }
-      write_out(o1, rC, p.colsum != nullptr);
+      write_out(o1, rC, p.colsum != nullptr || p.colstats != nullptr);
     }
     if (p.colsum) {
       // a lane owns 8 fixed columns for the rows it visited; lanes that share (lane & 7) share the columns
@@ -980,6 +991,25 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
         float t = csum[e];
         t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
         if (lane_e < 8 && gj_r < p.N) atomicAdd(p.colsum + gj_r + e, t);
+      }
+    }
+    if constexpr (MI == 8 && !HAS_AUX) {
+      if (p.colstats && i0 + wm * WM < p.M) {
+        // the wave's 128 rows x 64 columns: lanes that share (lane & 7) share 8 columns; lanes 0-7 store (sum, sum of squares)
+        // of their 8 columns = 64 contiguous bytes of block row (i0 + 128 wm) / 128
+        float st[16];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = csum[e], u = csq[e];
+          t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+          u += __shfl_xor(u, 8, 64); u += __shfl_xor(u, 16, 64); u += __shfl_xor(u, 32, 64);
+          st[2 * e] = t; st[2 * e + 1] = u;
+        }
+        if (lane_e < 8 && gj_r < p.N) {
+          float* o = p.colstats + ((int64_t)((i0 + wm * WM) >> 7) * p.N + gj_r) * 2;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(o + 4 * v) = f32x4{st[4 * v], st[4 * v + 1], st[4 * v + 2], st[4 * v + 3]};
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice reads have returned before the wave moves on
@@ -1412,11 +1442,11 @@ extern "C" int fcmf_gemm_ctx_tune(fcmf_gemm_ctx* ctx, int force_tile, int kb, in
 }
 extern "C" const char* fcmf_gemm_ctx_last_kernel(const fcmf_gemm_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
 
-struct ConvGeom { int C, logC, Hp, Wp, Ho, Wo, kw, stride; int64_t in_bytes; };
+struct ConvGeom { int C, logC, Hp, Wp, Ho, Wo, kw, stride; int64_t in_bytes; int logP; };
 
 static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
                      int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
-                     int out_dtype, int epilogue, int accumulate, void* stream, const ConvGeom* cv) {
+                     int out_dtype, int epilogue, int accumulate, void* stream, const ConvGeom* cv, float* colstats = nullptr) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0) return FCMF_ERR_ARG;
   const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
   char name_sink[96];
@@ -1438,11 +1468,11 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
                     (b_contig % 8 == 0) && (N % 4 == 0) && (ldc % 4 == 0) && K > 0 &&
                     // K-contiguous operands cannot zero-fill a partial k-tile; 32-bit byte offsets
                     (trans_a || K % BK == 0) && (trans_b || K % BK == 0) &&
-                    (((int64_t)(trans_a ? K : M) * lda) < (1ll << 30)) && (((int64_t)(trans_b ? K : N) * ldb) < (1ll << 30));
+                    (cv || ((int64_t)(trans_a ? K : M) * lda) < (1ll << 30)) && (((int64_t)(trans_b ? K : N) * ldb) < (1ll << 30));   // (cv: A's extent is the activation's, checked by the caller)
   if (fast) {
     GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, nullptr, nullptr,
-                 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (cv) { p.cv_C = cv->C; p.cv_logC = cv->logC; p.cv_Hp = cv->Hp; p.cv_Wp = cv->Wp; p.cv_Ho = cv->Ho; p.cv_Wo = cv->Wo; p.cv_kw = cv->kw; p.cv_inv_kw = (65536 + cv->kw - 1) / cv->kw; p.cv_stride = cv->stride; }
+                 0, 0, 0, 0, 0, 0, 0, 0, 0, colstats, 0};
+    if (cv) { p.cv_C = cv->C; p.cv_logC = cv->logC; p.cv_Hp = cv->Hp; p.cv_Wp = cv->Wp; p.cv_Ho = cv->Ho; p.cv_Wo = cv->Wo; p.cv_kw = cv->kw; p.cv_inv_kw = (65536 + cv->kw - 1) / cv->kw; p.cv_stride = cv->stride; p.cv_logP = cv->logP; }
     // bytes addressable through each operand: (rows - 1) * ld + contiguous extent
     p.a_bytes = cv ? (unsigned)cv->in_bytes : (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
     p.b_bytes = (unsigned)((((int64_t)(trans_b ? K : N) - 1) * ldb + (trans_b ? N : K)) * 2);
@@ -1464,6 +1494,12 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
                  ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (splittable && K >= 512));
     if (cfg.force_tile == 128) large = false;
     if (cfg.force_tile == 256 || cfg.force_tile == 192) large = tile_ok;
+    if (colstats) {       // block statistics exist in the 256-row bf16 kernels only: the caller falls back to a statistics pass
+      if (!(tile_ok && M >= 256 && N >= 256 && out_dtype == FCMF_BF16 && !trans_a && !trans_b && epilogue == FCMF_EPI_NONE &&
+            !accumulate && !aux))
+        return FCMF_ERR_UNSUPPORTED;
+      large = true;
+    }
     if (large) {
       const int slots = cfg.num_cus;
       // block tile rows: 256, or 192 where that removes a nearly empty last round (cost model: rounds x
@@ -1474,9 +1510,9 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
           const int64_t t = (int64_t)((M + rows - 1) / rows) * ((N + GB - 1) / GB);
           return (double)((t + slots - 1) / slots) * (nk * (rows / 256.0) + 8.0);
         };
-        if (cost(192) < 0.97 * cost(256)) tm = 192;
+        if (cost(192) < 0.97 * cost(256) && !colstats) tm = 192;
       }
-      if (cfg.force_tile == 192 && !trans_a && out_dtype == FCMF_BF16 && !accumulate) tm = 192;
+      if (cfg.force_tile == 192 && !trans_a && out_dtype == FCMF_BF16 && !accumulate && !colstats) tm = 192;
       const int tiles_l = ((M + tm - 1) / tm) * ((N + GB - 1) / GB);
       // 64-deep k-tiles where both operands are K-contiguous (whole-line DMA), the output is bf16 and K allows it
       // (weight gradients -- token-major operands, 512-B DMA rows already -- measured 4-8 % SLOWER on 64-deep k-tiles)
@@ -1530,6 +1566,7 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
       }
       return rc;
     }
+    if (colstats) return FCMF_ERR_UNSUPPORTED;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int ksplit = 1;
     // split K only where the output grid cannot fill the chip and C is an f32 accumulator
@@ -1551,7 +1588,7 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
     if (trans_a && !trans_b) return launch_bf16<true, false>(p, out_dtype, grid, st);
     return launch_bf16<true, true>(p, out_dtype, grid, st);
   }
-  if (cv) return FCMF_ERR_UNSUPPORTED;      // (the any-stride kernel has no implicit-convolution addressing)
+  if (cv || colstats) return FCMF_ERR_UNSUPPORTED;      // (the any-stride kernel has no implicit-convolution addressing, no block statistics)
   GenericParams g{A, B, C, bias, aux, M, N, K,
                   trans_a ? 1 : lda, trans_a ? lda : 1, trans_b ? 1 : ldb, trans_b ? ldb : 1, ldc,
                   epilogue, accumulate, colsum};
@@ -1585,7 +1622,7 @@ extern "C" int fcmf_gemm_fp8(fcmf_gemm_ctx* ctx, const void* A, const float* sa,
       (int64_t)N * ldb >= (1ll << 31) || M < 256 || N < 256)
     return FCMF_ERR_UNSUPPORTED;
   const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
-  GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, 0, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, sa, sb, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, 0, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, sa, sb, 0, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, 0};
   p.a_bytes = (unsigned)(((int64_t)M - 1) * lda + K);
   p.b_bytes = (unsigned)(((int64_t)N - 1) * ldb + K);
   p.c_bytes = (unsigned)c_extent;
@@ -1712,8 +1749,8 @@ extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void*
 // fcmf_bn_apply with `pad`); no patch matrix exists: the LDS-DMA of A's k-tile t reads the tap (ky, kx) of every row's
 // receptive field straight from the activation (per-lane offset = the field's origin, fixed per work item; the tap is a
 // wave-uniform scalar offset).
-extern "C" int fcmf_conv_gemm(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int C, int Ho,
-                              int Wo, int kh, int kw, int stride, int Cout, void* stream) {
+static int conv_gemm_impl(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, float* colstats, int n, int Hp, int Wp, int C, int Ho,
+                          int Wo, int kh, int kw, int stride, int Cout, void* stream) {
   if (!x || !w || !y || n <= 0 || Hp <= 0 || Wp <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || Cout <= 0)
     return FCMF_ERR_ARG;
   if ((C & (C - 1)) || C < 64 || kh * kw > 64) return FCMF_ERR_UNSUPPORTED;             // k-tiles must not straddle taps
@@ -1722,8 +1759,56 @@ extern "C" int fcmf_conv_gemm(fcmf_gemm_ctx* ctx, const void* x, const void* w, 
   if (in_bytes >= (1ll << 31) || M >= (1ll << 31)) return FCMF_ERR_UNSUPPORTED;
   int logC = 0;
   while ((1 << logC) < C) ++logC;
-  const ConvGeom cv{C, logC, Hp, Wp, Ho, Wo, kw, stride, in_bytes};
+  const ConvGeom cv{C, logC, Hp, Wp, Ho, Wo, kw, stride, in_bytes, logC};
   const int K = kh * kw * C;
+  return gemm_impl(ctx, x, w, y, nullptr, nullptr, nullptr, (int)M, Cout, K, K, K, Cout, 0, 0, FCMF_BF16, FCMF_BF16, FCMF_EPI_NONE, 0,
+                   stream, &cv, colstats);
+}
+extern "C" int fcmf_conv_gemm(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int C, int Ho,
+                              int Wo, int kh, int kw, int stride, int Cout, void* stream) {
+  return conv_gemm_impl(ctx, x, w, y, nullptr, n, Hp, Wp, C, Ho, Wo, kh, kw, stride, Cout, stream);
+}
+
+// The same two products with the BatchNorm statistics of the output as a by-product (ResNet trunks: every convolution feeds a
+// train-mode BatchNorm, whose statistics pass re-read the whole activation): stats [ceil(M / 128)][N][2] float32 <- (sum, sum of
+// squares) of each block of 128 output rows, per output channel, of the values AS STORED (bf16-rounded) -- plain stores from
+// the epilogue's registers, deterministic, no atomics.  fcmf_bn_stats_blocks turns them into the per-group totals.  bf16,
+// row-major A [M, K] and W [N, K], no epilogue; FCMF_ERR_UNSUPPORTED where the shape does not run on the 256-row persistent
+// kernel (M or N < 256, unaligned): the caller then runs fcmf_bn_stats over the output as before.
+extern "C" int fcmf_gemm_colstats(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, float* stats, int M, int N, int K,
+                                  int64_t lda, int64_t ldb, int64_t ldc, void* stream) {
+  if (!stats) return FCMF_ERR_ARG;
+  return gemm_impl(ctx, A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 0, FCMF_BF16, FCMF_BF16, FCMF_EPI_NONE, 0, stream,
+                   nullptr, stats);
+}
+extern "C" int fcmf_conv_gemm_colstats(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, float* stats, int n, int Hp, int Wp,
+                                       int C, int Ho, int Wo, int kh, int kw, int stride, int Cout, void* stream) {
+  if (!stats) return FCMF_ERR_ARG;
+  return conv_gemm_impl(ctx, x, w, y, stats, n, Hp, Wp, C, Ho, Wo, kh, kw, stride, Cout, stream);
+}
+
+// Implicit-GEMM convolution for inputs with FEW channels (the trunk's 7x7 / stride-2 stem on RGB crops, whose patch matrix was
+// 1.8 GB per 448 crops): x is NHWC with `pix` (a power of two, 4 for RGB0) elements per pixel, zero border included, and the
+// contraction walks, for every kernel row ky, ONE contiguous run of `run` elements (a power of two >= 32: kw x pix rounded up,
+// e.g. 8 pixels x 4 = 32 for kw = 7) that starts at pixel (oy * stride + ky, ox * stride): K = kh * run, w [Cout, kh * run] with
+// zeros where the run exceeds the kernel (kx >= kw, or the padding channel).  Same kernels as fcmf_conv_gemm: the tap offset is
+// ky rows of the input, the per-lane offset the run's first pixel.
+extern "C" int fcmf_conv_gemm_runs(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int pix, int run,
+                                   int Ho, int Wo, int kh, int stride, int Cout, void* stream) {
+  if (!x || !w || !y || n <= 0 || Hp <= 0 || Wp <= 0 || pix <= 0 || run <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || stride <= 0 || Cout <= 0)
+    return FCMF_ERR_ARG;
+  if ((pix & (pix - 1)) || (run & (run - 1)) || run < 32 || run % pix || kh > 64 || (stride * pix) % 8) return FCMF_ERR_UNSUPPORTED;
+  if ((Ho - 1) * stride + kh > Hp) return FCMF_ERR_ARG;
+  const int64_t in_elems = (int64_t)n * Hp * Wp * pix, M = (int64_t)n * Ho * Wo;
+  // the last run of the last row must end inside the buffer (runs may run past the end of THEIR row into the next one: those
+  // elements meet zero weights)
+  if ((((int64_t)(n - 1) * Hp + (Ho - 1) * stride + kh - 1) * Wp + (int64_t)(Wo - 1) * stride) * pix + run > in_elems) return FCMF_ERR_ARG;
+  if (in_elems * 2 >= (1ll << 31) || M >= (1ll << 31)) return FCMF_ERR_UNSUPPORTED;
+  int logC = 0, logP = 0;
+  while ((1 << logC) < run) ++logC;
+  while ((1 << logP) < pix) ++logP;
+  const ConvGeom cv{run, logC, Hp, Wp, Ho, Wo, 1, stride, in_elems * 2, logP};
+  const int K = kh * run;
   return gemm_impl(ctx, x, w, y, nullptr, nullptr, nullptr, (int)M, Cout, K, K, K, Cout, 0, 0, FCMF_BF16, FCMF_BF16, FCMF_EPI_NONE, 0,
                    stream, &cv);
 }

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libfcmf_hip.so")
 
 F32, BF16, F64 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_DGELU, EPI_DTANH, EPI_ADD = 0, 1, 2, 3, 4, 5
+ERR_UNSUPPORTED = -3      # FCMF_ERR_UNSUPPORTED: callers with a documented fallback entry point test for it
 
 _c = ctypes
 _vp, _i, _i64, _f, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -88,6 +89,12 @@ SIGNATURES = {
     "fcmf_bn_apply": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _vp],
     "fcmf_bn_apply_pad": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _vp],
     "fcmf_conv_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_conv_gemm_runs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_pack_rgb0": [_vp, _i, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
+    "fcmf_gemm_colstats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp],
+    "fcmf_conv_gemm_colstats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_bn_stats_blocks": [_vp, _vp, _i64, _i, _i, _vp],
+    "fcmf_bn_finalize_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _f, _f, _i, _i, _i, _i, _i, _vp],
     "fcmf_maxpool3x3s2": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "fcmf_adaptive_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_dp_unique_id": [_vp],

@@ -81,21 +81,79 @@ def padded_activation(N, Hh, Ww, C, dtype, device, pad=1):
     return buf
 
 
-def conv2d_implicit(xp, conv, N, Ho, Wo):
+FUSED_BN_APPLY = True     # tests flip this to compare fcmf_bn_finalize_apply with the separate finalize / apply kernels
+FUSED_BN_STATS = True     # tests flip this to compare the GEMM-epilogue block statistics with the separate statistics pass
+
+
+def _block_stats(rows, Cout, dtype, device):
+    """buffer for the (sum, sum of squares) per block of 128 output rows and channel that a colstats GEMM emits, or None where
+    that kernel does not apply (the caller then runs the statistics pass)"""
+    if not FUSED_BN_STATS or dtype != torch.bfloat16 or rows < 256 or Cout < 256 or Cout % 8:
+        return None
+    return torch.empty(((rows + 127) // 128, Cout, 2), dtype=torch.float32, device=device)
+
+
+def conv2d_implicit(xp, conv, N, Ho, Wo, stats=False):
     """xp [N, Hp, Wp, C] (zero border included where the convolution pads) -> [N, Ho, Wo, Cout] through fcmf_conv_gemm: no patch
-    matrix (the 3x3 / strided convolutions of the trunk spent 9 of 46.7 ms building them, 120 MB per crop)"""
+    matrix (the 3x3 / strided convolutions of the trunk spent 9 of 46.7 ms building them, 120 MB per crop).
+    stats: -> (y, block statistics for batchnorm_nhwc_ or None)"""
     kh, kw = conv.kernel_size
     Cout, C = conv.out_channels, xp.shape[3]
     wm, Kpad = _weight_matrix(conv, xp.dtype)
     assert Kpad == kh * kw * C
     y = torch.empty((N * Ho * Wo, Cout), dtype=xp.dtype, device=xp.device)
-    H.check(H.lib().fcmf_conv_gemm(H.gemm_ctx(), H.ptr(xp), H.ptr(wm), H.ptr(y), N, xp.shape[1], xp.shape[2], C, Ho, Wo, kh, kw,
-                                   conv.stride[0], Cout, H.stream()), "fcmf_conv_gemm")
+    blocks = _block_stats(N * Ho * Wo, Cout, xp.dtype, xp.device) if stats else None
+    if blocks is not None:
+        rc = H.lib().fcmf_conv_gemm_colstats(H.gemm_ctx(), H.ptr(xp), H.ptr(wm), H.ptr(y), H.ptr(blocks), N, xp.shape[1], xp.shape[2],
+                                             C, Ho, Wo, kh, kw, conv.stride[0], Cout, H.stream())
+        if rc == H.ERR_UNSUPPORTED:
+            blocks = None
+        else:
+            H.check(rc, "fcmf_conv_gemm_colstats")
+    if blocks is None:
+        H.check(H.lib().fcmf_conv_gemm(H.gemm_ctx(), H.ptr(xp), H.ptr(wm), H.ptr(y), N, xp.shape[1], xp.shape[2], C, Ho, Wo, kh, kw,
+                                       conv.stride[0], Cout, H.stream()), "fcmf_conv_gemm")
+    y = y.view(N, Ho, Wo, Cout)
+    return (y, blocks) if stats else y
+
+
+def _stem_runs_ok(conv, x, dt):
+    return (IMPLICIT_CONV and dt == torch.bfloat16 and conv.in_channels == 3 and conv.kernel_size[0] == conv.kernel_size[1] <= 8
+            and conv.stride[0] == 2 and x.dtype in (torch.float32, torch.float64, torch.bfloat16))
+
+
+def conv2d_stem(v, conv):
+    """the stem (conv1: k x k, k <= 8, stride 2, 3 input channels) without a patch matrix: v = the crops as a strided NHWC view
+    [N, H, W, 3] of any float dtype.  fcmf_pack_rgb0 writes them as bf16 RGB0 pixels into a zero-bordered buffer, and
+    fcmf_conv_gemm_runs contracts, per kernel row, one 32-element run (8 pixels x 4) of it against w [Cout, kh, 8, 4] (zeros for
+    the 8th pixel and the 4th channel).  im2col + GEMM read / wrote 4.1 GB per 448 crops here, this path 0.4 GB."""
+    N, Hh, Ww, _ = v.shape
+    k, pad, Cout = conv.kernel_size[0], conv.padding[0], conv.out_channels
+    Ho, Wo = (Hh + 2 * pad - k) // 2 + 1, (Ww + 2 * pad - k) // 2 + 1
+    # (one spare column on the right: the 8-pixel run of the last output pixel of a row may end past the padded row)
+    Wp = max(Ww + 2 * pad, (Wo - 1) * 2 + 8)
+    key = ("rgb0", N, Hh, Ww, pad, str(v.device))
+    buf = _pad_cache.get(key)
+    if buf is None:
+        buf = _pad_cache[key] = torch.zeros((N, Hh + 2 * pad, Wp, 4), dtype=torch.bfloat16, device=v.device)
+    sn, sh, sw, sc = v.stride()
+    # (dst rows are Wp pixels wide: the pack kernel takes the padded width through W + 2 pad, so hand it the buffer's own geometry)
+    H.check(H.lib().fcmf_pack_rgb0(H.ptr(v), H.dt(v), H.ptr(buf), N, Hh, Ww, sn, sh, sw, sc, pad, Wp, H.stream()), "fcmf_pack_rgb0")
+
+    def build(src):
+        w = torch.zeros((Cout, k, 8, 4), dtype=torch.float32, device=src.device)
+        w[:, :, :k, :3] = src.detach().float().permute(0, 2, 3, 1)            # [Cout, 3, ky, kx] -> [Cout, ky, kx, c]
+        return ops.cast(w.view(Cout, k * 32).contiguous(), torch.bfloat16)
+    wm = ops.shadows.derived(conv.weight, ("stem_runs", torch.bfloat16), build)
+    y = torch.empty((N * Ho * Wo, Cout), dtype=torch.bfloat16, device=v.device)
+    H.check(H.lib().fcmf_conv_gemm_runs(H.gemm_ctx(), H.ptr(buf), H.ptr(wm), H.ptr(y), N, Hh + 2 * pad, Wp, 4, 32, Ho, Wo, k, 2, Cout,
+                                        H.stream()), "fcmf_conv_gemm_runs")
     return y.view(N, Ho, Wo, Cout)
 
 
-def conv2d_nhwc(x, conv, src_strides=None):
-    """x [N,H,W,C] (or any layout with `src_strides` = element strides of (n,h,w,c)) -> [N,Ho,Wo,Cout]"""
+def conv2d_nhwc(x, conv, src_strides=None, stats=False):
+    """x [N,H,W,C] (or any layout with `src_strides` = element strides of (n,h,w,c)) -> [N,Ho,Wo,Cout]
+    stats: -> (y, block statistics of y for batchnorm_nhwc_, or None where the GEMM cannot emit them)"""
     if conv.bias is not None or conv.groups != 1 or conv.dilation != (1, 1):
         raise H.HipLibraryError("conv2d_nhwc: bias-free, ungrouped, undilated convolutions only (ResNet trunk)")
     dt = ops.compute_dtype()
@@ -110,63 +168,80 @@ def conv2d_nhwc(x, conv, src_strides=None):
         A = x.view(rows, C)
     elif (kh == 1 and kw == 1 and pad == 0 and src_strides is None and x.dtype == dt and x.is_contiguous() and _implicit_ok(C, dt)
           and not torch.is_grad_enabled()):
-        return conv2d_implicit(x, conv, N, Ho, Wo)          # strided 1x1 shortcut: rows are gathered by the GEMM's DMA
+        return conv2d_implicit(x, conv, N, Ho, Wo, stats=stats)          # strided 1x1 shortcut: rows are gathered by the GEMM's DMA
     else:
         A = torch.empty((rows, Kpad), dtype=dt, device=x.device)
         sn, sh, sw, sc = src_strides if src_strides is not None else x.stride()
         H.check(H.lib().fcmf_conv_im2col(H.ptr(x), H.dt(x), H.ptr(A), H.dt(A), N, Hh, Ww, C, sn, sh, sw, sc, kh, kw, st,
                                          pad, Kpad, H.stream()), "fcmf_conv_im2col")
     y = torch.empty((rows, Cout), dtype=dt, device=x.device)
-    ops.gemm(A, wm, y, rows, Cout, Kpad, Kpad, Kpad, Cout, 0, 0)
-    return y.view(N, Ho, Wo, Cout)
+    blocks = _block_stats(rows, Cout, dt, x.device) if stats else None
+    if blocks is not None:
+        rc = H.lib().fcmf_gemm_colstats(H.gemm_ctx(), H.ptr(A), H.ptr(wm), H.ptr(y), H.ptr(blocks), rows, Cout, Kpad, Kpad, Kpad, Cout,
+                                        H.stream())
+        if rc == H.ERR_UNSUPPORTED:
+            blocks = None
+        else:
+            H.check(rc, "fcmf_gemm_colstats")
+    if blocks is None:
+        ops.gemm(A, wm, y, rows, Cout, Kpad, Kpad, Kpad, Cout, 0, 0)
+    y = y.view(N, Ho, Wo, Cout)
+    return (y, blocks) if stats else y
 
 
-def batchnorm_nhwc_(y, bn, groups=1, res=None, relu=False, out=None, save=None, out_pad=0):
+def batchnorm_nhwc_(y, bn, groups=1, res=None, relu=False, out=None, save=None, out_pad=0, blocks=None):
     """BatchNorm2d (+ residual, + ReLU) of y [N,H,W,C], in place (or into `out`); training mode: per-group batch
     statistics and `groups` running-statistics updates (module docstring).  save: dict that receives mean / rstd /
-    groups / training for the backward."""
+    groups / training for the backward.  blocks: the block statistics the producing convolution emitted (conv2d_nhwc(...,
+    stats=True)): the statistics pass over y is skipped when every group is a whole number of 128-row blocks."""
     N, Hh, Ww, C = y.shape
     rows = N * Hh * Ww
     L, st = H.lib(), H.stream()
     dev = y.device
     training = bn.training or not bn.track_running_stats
-    mean = rstd = None
+    mean = rstd = sums = None
     if training:
         if N % groups != 0:
             raise H.HipLibraryError(f"grouped BatchNorm: {N} crops do not split into {groups} equal groups")
         rpg = rows // groups
         sums = torch.empty(L.fcmf_bn_stats_workspace(rpg, groups, C), dtype=torch.float64, device=dev)
-        scale = torch.empty((groups, C), dtype=torch.float32, device=dev)
-        shift = torch.empty((groups, C), dtype=torch.float32, device=dev)
-        if save is not None:
-            mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
-        H.check(L.fcmf_bn_stats(H.ptr(y), H.ptr(sums), rpg, groups, C, H.dt(y), st), "fcmf_bn_stats")
+        if blocks is not None and rpg % 128 == 0:
+            H.check(L.fcmf_bn_stats_blocks(H.ptr(blocks), H.ptr(sums), rpg, groups, C, st), "fcmf_bn_stats_blocks")
+        else:
+            H.check(L.fcmf_bn_stats(H.ptr(y), H.ptr(sums), rpg, groups, C, H.dt(y), st), "fcmf_bn_stats")
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
         if bn.track_running_stats:
             rm, rv = bn.running_mean, bn.running_var
         else:
             rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-        H.check(L.fcmf_bn_finalize(H.ptr(sums), H.ptr(bn.weight), H.ptr(bn.bias), H.ptr(rm), H.ptr(rv), H.ptr(scale),
-                                   H.ptr(shift), H.ptr(mean), H.ptr(rstd), C, groups, rpg, mom, float(bn.eps), st),
-                "fcmf_bn_finalize")
         if bn.track_running_stats and bn.num_batches_tracked is not None:
             bn._pending_batches = getattr(bn, "_pending_batches", 0) + groups      # flushed lazily (one add, not 155 per pass)
+        shape = (groups, C)
     else:
-        rpg, groups = rows, 1
-        scale = torch.empty(C, dtype=torch.float32, device=dev)
-        shift = torch.empty(C, dtype=torch.float32, device=dev)
-        if save is not None:
-            mean, rstd = torch.empty_like(scale), torch.empty_like(scale)
-        H.check(L.fcmf_bn_finalize(0, H.ptr(bn.weight), H.ptr(bn.bias), H.ptr(bn.running_mean), H.ptr(bn.running_var),
-                                   H.ptr(scale), H.ptr(shift), H.ptr(mean), H.ptr(rstd), C, 1, 0, 0.0, float(bn.eps), st),
-                "fcmf_bn_finalize")
+        rpg, groups, mom = rows, 1, 0.0
+        rm, rv = bn.running_mean, bn.running_var
+        shape = (C,)
+    if save is not None:
+        mean, rstd = (torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(2))
     z = y if out is None else out
-    if out_pad > 0:           # `out` is a padded_activation buffer: the interior is written, the zero border stays
-        H.check(L.fcmf_bn_apply_pad(H.ptr(y), H.ptr(res), H.ptr(z), H.ptr(scale), H.ptr(shift), rows, C, rpg, int(relu), Hh, Ww,
-                                    out_pad, H.dt(y), st), "fcmf_bn_apply_pad")
+    # scale / shift derivation + normalisation (+ residual, ReLU, zero-bordered output) in one launch where the shape allows
+    rc = H.ERR_UNSUPPORTED
+    if FUSED_BN_APPLY:
+        rc = L.fcmf_bn_finalize_apply(H.ptr(y), H.ptr(res), H.ptr(z), H.ptr(sums), H.ptr(bn.weight), H.ptr(bn.bias), H.ptr(rm), H.ptr(rv),
+                                      H.ptr(mean), H.ptr(rstd), C, groups, rpg, mom, float(bn.eps), int(relu), Hh, Ww, out_pad, H.dt(y), st)
+    if rc == H.ERR_UNSUPPORTED:
+        scale = torch.empty(shape, dtype=torch.float32, device=dev)
+        shift = torch.empty(shape, dtype=torch.float32, device=dev)
+        H.check(L.fcmf_bn_finalize(H.ptr(sums), H.ptr(bn.weight), H.ptr(bn.bias), H.ptr(rm), H.ptr(rv), H.ptr(scale), H.ptr(shift),
+                                   H.ptr(mean), H.ptr(rstd), C, groups, rpg if training else 0, mom, float(bn.eps), st), "fcmf_bn_finalize")
+        if out_pad > 0:           # `out` is a padded_activation buffer: the interior is written, the zero border stays
+            H.check(L.fcmf_bn_apply_pad(H.ptr(y), H.ptr(res), H.ptr(z), H.ptr(scale), H.ptr(shift), rows, C, rpg, int(relu), Hh, Ww,
+                                        out_pad, H.dt(y), st), "fcmf_bn_apply_pad")
+        else:
+            H.check(L.fcmf_bn_apply(H.ptr(y), H.ptr(res), H.ptr(z), H.ptr(scale), H.ptr(shift), rows, C, rpg, int(relu), H.dt(y),
+                                    st), "fcmf_bn_apply")
     else:
-        H.check(L.fcmf_bn_apply(H.ptr(y), H.ptr(res), H.ptr(z), H.ptr(scale), H.ptr(shift), rows, C, rpg, int(relu), H.dt(y),
-                                st), "fcmf_bn_apply")
+        H.check(rc, "fcmf_bn_finalize_apply")
     if save is not None:
         save.update(mean=mean, rstd=rstd, groups=groups, training=training, rpg=rpg)
     return z
@@ -391,35 +466,37 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward_nhwc(self, x, groups):
-        y1 = conv2d_nhwc(x, self.conv1)
+        # (every convolution hands the statistics of its output to the BatchNorm that follows it: stats=True)
+        y1, b1 = conv2d_nhwc(x, self.conv1, stats=True)
         N, Hh, Ww, C = y1.shape
         if _implicit_ok(C, y1.dtype) and not torch.is_grad_enabled():
             # bn1 + relu write straight into the zero-bordered input of the 3x3 convolution, which then runs as an implicit GEMM
             zp = padded_activation(N, Hh, Ww, C, y1.dtype, y1.device)
-            batchnorm_nhwc_(y1, self.bn1, groups, relu=True, out=zp, out_pad=1)
+            batchnorm_nhwc_(y1, self.bn1, groups, relu=True, out=zp, out_pad=1, blocks=b1)
             st = self.conv2.stride[0]
-            out = conv2d_implicit(zp, self.conv2, N, (Hh - 1) // st + 1, (Ww - 1) // st + 1)
+            out, b2 = conv2d_implicit(zp, self.conv2, N, (Hh - 1) // st + 1, (Ww - 1) // st + 1, stats=True)
         else:
-            out = conv2d_nhwc(batchnorm_nhwc_(y1, self.bn1, groups, relu=True), self.conv2)
-        out = batchnorm_nhwc_(out, self.bn2, groups, relu=True)
-        out = conv2d_nhwc(out, self.conv3)
+            out, b2 = conv2d_nhwc(batchnorm_nhwc_(y1, self.bn1, groups, relu=True, blocks=b1), self.conv2, stats=True)
+        out = batchnorm_nhwc_(out, self.bn2, groups, relu=True, blocks=b2)
+        out, b3 = conv2d_nhwc(out, self.conv3, stats=True)
         if self.downsample is not None:
-            x = batchnorm_nhwc_(conv2d_nhwc(x, self.downsample[0]), self.downsample[1], groups)
-        return batchnorm_nhwc_(out, self.bn3, groups, res=x, relu=True)       # bn3 -> += identity -> relu, one pass
+            yd, bd = conv2d_nhwc(x, self.downsample[0], stats=True)
+            x = batchnorm_nhwc_(yd, self.downsample[1], groups, blocks=bd)
+        return batchnorm_nhwc_(out, self.bn3, groups, res=x, relu=True, blocks=b3)       # bn3 -> += identity -> relu, one pass
 
     def forward_rec(self, x, groups, tape):
         """forward_nhwc that keeps what the backward needs (raw convolution outputs are NOT overwritten)"""
         r = {"x": x, "blk": self}
         for i, (conv, bn, src) in enumerate(((self.conv1, self.bn1, "x"), (self.conv2, self.bn2, "z1"), (self.conv3, self.bn3, "z2")), 1):
-            y = conv2d_nhwc(r[src], conv)
+            y, blk = conv2d_nhwc(r[src], conv, stats=True)
             r[f"y{i}"], r[f"s{i}"] = y, {}
             if i < 3:
-                r[f"z{i}"] = batchnorm_nhwc_(y, bn, groups, relu=True, out=torch.empty_like(y), save=r[f"s{i}"])
+                r[f"z{i}"] = batchnorm_nhwc_(y, bn, groups, relu=True, out=torch.empty_like(y), save=r[f"s{i}"], blocks=blk)
         idn = x
         if self.downsample is not None:
-            r["yd"], r["sd"] = conv2d_nhwc(x, self.downsample[0]), {}
-            idn = batchnorm_nhwc_(r["yd"], self.downsample[1], groups, out=torch.empty_like(r["yd"]), save=r["sd"])
-        r["z3"] = batchnorm_nhwc_(r["y3"], self.bn3, groups, res=idn, relu=True, out=torch.empty_like(r["y3"]), save=r["s3"])
+            (r["yd"], bd), r["sd"] = conv2d_nhwc(x, self.downsample[0], stats=True), {}
+            idn = batchnorm_nhwc_(r["yd"], self.downsample[1], groups, out=torch.empty_like(r["yd"]), save=r["sd"], blocks=bd)
+        r["z3"] = batchnorm_nhwc_(r["y3"], self.bn3, groups, res=idn, relu=True, out=torch.empty_like(r["y3"]), save=r["s3"], blocks=blk)
         tape.append(r)
         return r["z3"]
 
@@ -505,7 +582,10 @@ class ResNet(nn.Module):
         """tape is None: activations are normalised in place, nothing is kept; else: recording forward for TrunkFn"""
         xs = x if x.dtype in (torch.float32, torch.bfloat16) else x.float()
         v = xs.permute(0, 2, 3, 1)                                       # strided NHWC view of the NCHW crops
-        y = conv2d_nhwc(v, self.conv1, src_strides=v.stride())
+        if tape is None and _stem_runs_ok(self.conv1, v, ops.compute_dtype()):
+            y = conv2d_stem(v, self.conv1)
+        else:
+            y = conv2d_nhwc(v, self.conv1, src_strides=v.stride())
         if tape is None:
             y = batchnorm_nhwc_(y, self.bn1, groups, relu=True)
             y = maxpool3x3s2_nhwc(y)

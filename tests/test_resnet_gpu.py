@@ -287,3 +287,127 @@ def test_implicit_gemm_convolution_matches_patch_matrix_and_torch(dev, C, Cout, 
     finally:
         R.IMPLICIT_CONV = True
         _set(torch.float32)
+
+
+@pytest.mark.parametrize("C,Cout,k,stride,N,hw,groups", [(64, 256, 1, 1, 8, 16, 2), (256, 256, 3, 1, 6, 16, 3), (512, 1024, 1, 2, 8, 16, 4),
+                                                         (128, 512, 1, 1, 3, 20, 1), (256, 1024, 1, 1, 7, 14, 7)])
+def test_convolution_emits_the_batchnorm_statistics_of_its_output(dev, C, Cout, k, stride, N, hw, groups):
+    """fcmf_gemm_colstats / fcmf_conv_gemm_colstats + fcmf_bn_stats_blocks against the convolution followed by the separate
+    statistics pass (fcmf_bn_stats): the output tensor is bit-identical; the block statistics are the exact f32 sums of the
+    STORED bf16 values over 128 rows (checked against a float64 sum of the output); the BatchNorm that consumes them gives the
+    same result as the two-pass path to bf16 rounding, running statistics included.  Cases: 1x1 plain GEMM, 3x3 implicit, strided
+    1x1 implicit, a row count that is no multiple of 128 (ragged last block; the group then falls back to the pass), 7 groups."""
+    from fcmf_framework import _hip as H, ops, resnet as R
+    _set(torch.bfloat16)
+    try:
+        pad = 1 if k == 3 else 0
+        conv = R.Conv2d(C, Cout, k, stride=stride, padding=pad, bias=False).to(dev)
+        conv.weight.data = _rand(conv.weight.shape, 1, (2.0 / (C * k * k)) ** 0.5).to(dev)
+        x = (_rand((N, hw, hw, C), 2) + 0.3).to(dev).bfloat16()
+        Ho = (hw + 2 * pad - k) // stride + 1
+        rows = N * Ho * Ho
+
+        def run(fused):
+            R.FUSED_BN_STATS = fused
+            bn = R.BatchNorm2d(Cout).to(dev)
+            bn.weight.data = _rand((Cout,), 3).to(dev) * 0.1 + 1.0
+            bn.bias.data = _rand((Cout,), 4).to(dev) * 0.1
+            bn.train()
+            with torch.no_grad():
+                if k == 3:
+                    xp = R.padded_activation(N, hw, hw, C, x.dtype, dev)
+                    one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+                    H.check(H.lib().fcmf_bn_apply_pad(H.ptr(x), None, H.ptr(xp), H.ptr(one), H.ptr(zero), N * hw * hw, C, N * hw * hw, 0, hw, hw, 1,
+                                                      H.dt(x), H.stream()), "fcmf_bn_apply_pad")
+                    y, blocks = R.conv2d_implicit(xp, conv, N, Ho, Ho, stats=True)
+                else:
+                    y, blocks = R.conv2d_nhwc(x, conv, stats=True)
+                kern = H.last_gemm_kernel()
+                z = R.batchnorm_nhwc_(y, bn, groups, relu=True, out=torch.empty_like(y), blocks=blocks)
+            return y, blocks, z, bn.running_mean.clone(), bn.running_var.clone(), kern
+
+        y0, b0, z0, rm0, rv0, _ = run(False)
+        y1, b1, z1, rm1, rv1, kern = run(True)
+        assert b0 is None and b1 is not None and "tile256" in kern, kern
+        assert torch.equal(y0, y1)
+        yf = y1.view(rows, Cout).double().cpu()
+        nb = (rows + 127) // 128
+        assert b1.shape == (nb, Cout, 2)
+        padded = torch.zeros(nb * 128, Cout, dtype=torch.float64)
+        padded[:rows] = yf
+        want_s, want_q = padded.view(nb, 128, Cout).sum(1), (padded ** 2).view(nb, 128, Cout).sum(1)
+        assert max_err(b1[..., 0].cpu().double(), want_s) < 1e-5 * want_s.abs().max().item()
+        assert max_err(b1[..., 1].cpu().double(), want_q) < 1e-5 * want_q.abs().max().item()
+        assert max_err(z1, z0) <= 2 ** -7 * z0.float().abs().max().item()
+        assert max_err(rm1, rm0) < 1e-5 and max_err(rv1, rv0) < 1e-5
+    finally:
+        R.FUSED_BN_STATS = True
+        _set(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,groups,N,hw,pad,with_res,training", [(64, 7, 14, 9, 1, False, True), (256, 2, 4, 7, 0, True, True), (2048, 3, 3, 5, 0, True, True),
+                                                                  (512, 1, 5, 6, 1, False, False), (4, 2, 4, 5, 0, False, True)])
+def test_batchnorm_finalize_and_apply_in_one_launch(dev, dtype, C, groups, N, hw, pad, with_res, training):
+    """fcmf_bn_finalize_apply against fcmf_bn_finalize + fcmf_bn_apply(_pad): the same arithmetic per element, so the normalised
+    tensor and mean / rstd are bit-identical, the running statistics equal to one ulp; zero-bordered output, residual + ReLU, eval mode, 7 groups,
+    and shapes the fused kernel refuses (bf16 with C = 4: less than one 16-byte vector; float32 with C = 2048: 512 lanes per row) that take the two-kernel path
+    by themselves."""
+    from fcmf_framework import resnet as R
+    _set(dtype)
+    try:
+        x = (_rand((N, hw, hw, C), 1) * 1.3 + 0.2).to(dev).to(dtype)
+        res = (_rand((N, hw, hw, C), 2)).to(dev).to(dtype) if with_res else None
+        outs = []
+        for fused in (False, True):
+            R.FUSED_BN_APPLY = fused
+            bn = R.BatchNorm2d(C).to(dev)
+            bn.weight.data = _rand((C,), 3).to(dev) * 0.1 + 1.0
+            bn.bias.data = _rand((C,), 4).to(dev) * 0.1
+            bn.running_mean.data = _rand((C,), 5).to(dev) * 0.1
+            bn.running_var.data = torch.rand(C, generator=torch.Generator().manual_seed(6)).to(dev) + 0.5
+            bn.train(training)
+            save = {}
+            with torch.no_grad():
+                out = R.padded_activation(N, hw, hw, C, dtype, dev).clone() if pad else torch.empty_like(x)
+                z = R.batchnorm_nhwc_(x.clone(), bn, groups if training else 1, res=res, relu=True, out=out, save=save, out_pad=pad)
+            outs.append((z, save["mean"], save["rstd"], bn.running_mean.clone(), bn.running_var.clone()))
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(a, b)
+        for a, b in zip(outs[0][3:], outs[1][3:]):       # (running statistics: the two kernels contract a*b + c*d differently -- an ulp per group)
+            assert max_err(a, b) <= 1e-6 * max(1.0, b.abs().max().item())
+        if pad:
+            z = outs[1][0]
+            assert not z[:, 0].any() and not z[:, -1].any() and not z[:, :, 0].any() and not z[:, :, -1].any()
+    finally:
+        R.FUSED_BN_APPLY = True
+        _set(torch.float32)
+
+
+@pytest.mark.parametrize("N,hw,src", [(3, 64, torch.float32), (2, 37, torch.float64), (5, 224, torch.float32), (4, 30, torch.bfloat16)])
+def test_stem_convolution_without_patch_matrix(dev, N, hw, src):
+    """conv1 (7x7, stride 2, pad 3, RGB) through fcmf_pack_rgb0 + fcmf_conv_gemm_runs (one 8-pixel x RGB0 run per kernel row, zero
+    weights for the 8th pixel and the padding channel) against the patch-matrix path on the same bf16-rounded crops and against
+    F.conv2d in float32; NCHW crops read through their strides, odd sizes (the last run of a row needs the spare column),
+    float64 crops (the reference's dataset dtype), border of the packed buffer still zero afterwards."""
+    from fcmf_framework import ops, resnet as R
+    _set(torch.bfloat16)
+    try:
+        conv = R.Conv2d(3, 64, 7, stride=2, padding=3, bias=False).to(dev)
+        conv.weight.data = _rand(conv.weight.shape, 1, (2.0 / 147) ** 0.5).to(dev)
+        x = _rand((N, 3, hw, hw + 2), 2).to(src).to(dev)                          # NCHW, as the dataset hands the crops over
+        v = x.permute(0, 2, 3, 1)
+        with torch.no_grad():
+            assert R._stem_runs_ok(conv, v, ops.compute_dtype())
+            y_runs = R.conv2d_stem(v, conv)
+            ve = v if src != torch.float64 else x.float().permute(0, 2, 3, 1)   # (the patch-matrix kernel takes float32 / bf16 crops)
+            y_exp = R.conv2d_nhwc(ve, conv, src_strides=ve.stride())
+        assert y_runs.shape == y_exp.shape
+        scale = y_exp.float().abs().max().item()
+        assert max_err(y_runs, y_exp) <= 2 ** -7 * scale
+        ref = F.conv2d(x.float().cpu().bfloat16().float(), conv.weight.data.float().cpu(), stride=2, padding=3).permute(0, 2, 3, 1)
+        assert max_err(y_runs, ref) < 2e-2 * ref.abs().max().item()
+        buf = R._pad_cache[("rgb0", N, hw, hw + 2, 3, str(v.device))]
+        assert not buf[:, :3].any() and not buf[:, -3:].any() and not buf[:, :, :3].any() and not buf[:, :, hw + 2 + 3:].any() and not buf[..., 3].any()
+    finally:
+        _set(torch.float32)
