@@ -372,6 +372,14 @@ int fcmf_bn_finalize_apply(const void* x, const void* res, void* y, const double
  * bf16, C a power of two >= 64, w [Cout, kh*kw*C] row-major in (ky, kx, c) order, y [n*Ho*Wo, Cout]. */
 int fcmf_conv_gemm(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int C, int Ho, int Wo,
                    int kh, int kw, int stride, int Cout, void* stream);
+/* `count` same-shape weight gradients in one launch: C_i [M, N] float32 (+)= A_i^T B_i with A_i = dY_i [K, M], B_i = X_i [K, N]
+ * (bf16, K = tokens) -- nn.Linear's weight gradient (loss.backward(), run_multimodal_fcmf.py:466) for the layers of an encoder,
+ * which the host queues during the backward pass and multiplies together: the tiles of all matrices form ONE work list for the
+ * persistent 256 x 256 kernel (a 768 x 768 gradient alone is 9 tiles; alone it fills the chip only through a 28-way split of K
+ * and a 64 MB partial-tile round trip).  A / B / C: host arrays of `count` device pointers.  accumulate as fcmf_gemm.  Shapes the
+ * persistent kernel does not take (M or N < 256, unaligned) and count == 1 run as `count` fcmf_gemm calls: same results. */
+int fcmf_gemm_dw_batched(fcmf_gemm_ctx* ctx, int count, const void* const* A, const void* const* B, void* const* C, int M, int N, int K,
+                         int64_t lda, int64_t ldb, int64_t ldc, int accumulate, void* stream);
 /* Implicit-GEMM convolution for inputs with few channels -- the trunk's stem, conv1 = 7x7 / stride 2 / pad 3 on RGB crops
  * (torchvision resnet152.conv1 driven by resnet_utils.py:13-24), whose patch matrix was 1.8 GB per 448 crops: x is NHWC bf16 with
  * `pix` elements per pixel (a power of two: 4 = RGB0, written by fcmf_pack_rgb0) and its zero border; for every kernel row ky the

@@ -31,7 +31,12 @@ struct GemmParams {
   // log2 of the element distance between neighbouring pixels of the convolution's input (= cv_logC for an NHWC activation
   // whose k-tiles walk the channels of one tap; smaller for fcmf_conv_gemm_runs, whose "tap" is a run of several whole pixels)
   int cv_logP;
+  // batched weight gradients (gemm_bf16_dw_batched_kernel): the `tiles` output tiles cover `tiles / tiles_per_mat` same-shape
+  // matrices, tile t belongs to matrix t / tiles_per_mat whose operand / output pointers come from the BatchPtrs argument
+  int tiles_per_mat;
 };
+constexpr int BATCH_MAX = 32;      // matrices per launch (the three pointer tables travel as a kernel argument: 768 bytes)
+struct BatchPtrs { const void* A[BATCH_MAX]; const void* B[BATCH_MAX]; void* C[BATCH_MAX]; };
 
 // element offset of the receptive-field origin of output row `row` in the (padded) input
 __device__ __forceinline__ int64_t conv_row_base(const GemmParams& p, int row) {
@@ -195,6 +200,9 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int x0, int lane) {
 
 template <bool A_TR, bool B_TR, typename TC>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+  // (an 8-stage ring -- seven k-tiles in flight -- was tried for the grids that leave most CUs empty, the IAOG decoder's 768-row
+  //  GEMMs: 36 workgroups, 24 k-tiles, 20 us.  No gain: those launches are a serial chain of per-k-tile fixed costs -- wait, barrier,
+  //  DMA issue, fragment reads -- not of DMA round trips.)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NSTAGE x (A tile + B tile) = 64 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -466,8 +474,9 @@ __device__ __forceinline__ void wait_vm(u32x4 (&r)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
 }
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-template <bool A_TR, bool B_TR, typename TC, int EPI, int MI, int KB, bool FP8 = false>
-__device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
+template <bool A_TR, bool B_TR, typename TC, int EPI, int MI, int KB, bool FP8 = false, bool BATCH = false>
+__device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, const BatchPtrs* bp = nullptr) {
+  static_assert(!BATCH || (A_TR && B_TR && sizeof(TC) == 4 && MI == 8 && KB == 32), "batched: the weight-gradient kernel");
   static_assert(MI == 8 || (MI == 6 && !A_TR && sizeof(TC) == 2), "192-row tiles: row-major A, bf16 output");
   static_assert(KB == 32 || KB == 64, "k-tile depth");
   static_assert(!FP8 || (KB == 64 && !A_TR && !B_TR && sizeof(TC) == 2), "fp8: K-contiguous operands, bf16 output");
@@ -506,7 +515,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
   constexpr bool ASM_DMA = A_TR || B_TR;    // (see dma16_asm: transposed fragment reads must not see a compiler-visible LDS-DMA)
-  [[maybe_unused]] const u32x4 wA = rsrc_words(p.A, p.a_bytes), wB = rsrc_words(p.B, p.b_bytes);
+  [[maybe_unused]] u32x4 wA = rsrc_words(p.A, p.a_bytes), wB = rsrc_words(p.B, p.b_bytes);   // (BATCH: re-pointed per work item)
   const unsigned a_step = A_TR ? (unsigned)(KB * p.lda * 2) : (unsigned)(KB * 2);
   const unsigned b_step = B_TR ? (unsigned)(KB * p.ldb * 2) : (unsigned)(KB * 2);
   // Per-lane LDS offsets are computed ONCE; fragment f of a K-contiguous operand is a constant 1 KiB
@@ -541,12 +550,14 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     return r;
   };
 
-  struct Item { int i0, j0, kt_begin, nkt, zsplit; };
+  struct Item { int i0, j0, kt_begin, nkt, zsplit, batch; };
   auto decode = [&](int item) -> Item {
     const int zsplit = item / p.tiles, tile = item - zsplit * p.tiles;
-    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    int local = tile, batch = 0;
+    if constexpr (BATCH) { batch = tile / p.tiles_per_mat; local = tile - batch * p.tiles_per_mat; }
+    const int tile_m = local / tiles_n, tile_n = local % tiles_n;
     const int kb = zsplit * p.ktiles_per_split;
-    return Item{tile_m * TM, tile_n * GB, kb, min(nk_total, kb + p.ktiles_per_split) - kb, zsplit};
+    return Item{tile_m * TM, tile_n * GB, kb, min(nk_total, kb + p.ktiles_per_split) - kb, zsplit, batch};
   };
   // KB = 32 ring: k-tile t of the current item lives in stage (base + t) % 4 (A tile, then B tile); `base` runs on across
   // items.  Three k-tiles in flight.
@@ -624,6 +635,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0), expcnt / lgkmcnt untouched
   }
   const Item w = decode(item);
+  if constexpr (BATCH) { wA = rsrc_words(bp->A[w.batch], p.a_bytes); wB = rsrc_words(bp->B[w.batch], p.b_bytes); }
   Src src = sources(w);
 #pragma unroll
   for (int j = 0; j < A_PIECES; ++j) asm volatile("" : "+v"(src.a[j]), "+v"(src.b[j]));   // materialised here, not re-derived per k-tile
@@ -806,7 +818,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p) {
     for (int rnd = EARLY_AUX ? 2 : 0; rnd < (EARLY_AUX ? NRND : 2); ++rnd) load_aux(rnd);
   }
 
-  TC* C = reinterpret_cast<TC*>(p.C);
+  TC* C = reinterpret_cast<TC*>(BATCH ? bp->C[w.batch] : p.C);
   if constexpr (sizeof(TC) == 2) {
     // ---- wave-local bf16 epilogue ------------------------------------------------------------------
     // Every wave of the workgroup has passed barrier nkt-1, so every stage except that of tile nkt-1
@@ -1289,6 +1301,12 @@ template <bool A_TR, bool B_TR, typename TC, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmParams p) {
   gemm_bf16_tile256_body<A_TR, B_TR, TC, EPI, 8, 32>(p);
 }
+// up to BATCH_MAX same-shape weight gradients dW_i (+)= dY_i^T X_i in ONE launch: the tiles of all matrices form one work list
+// (a layer's 768 x 768 gradient alone is 9 tiles: it filled the chip only through a 28-way split of K, whose partial tiles then
+// cost a reduce pass per matrix)
+__global__ __launch_bounds__(512, 1) void gemm_bf16_dw_batched_kernel(GemmParams p, BatchPtrs bp) {
+  gemm_bf16_tile256_body<true, true, float, FCMF_EPI_NONE, 8, 32, false, true>(p, &bp);
+}
 template <bool B_TR, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_tile192_kernel(GemmParams p) {
   gemm_bf16_tile256_body<false, B_TR, bf16_t, EPI, 6, 32>(p);
@@ -1374,6 +1392,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_frag_kernel(const float* __
     const int col = (tile % tiles_n) * GB + wn * 64 + fj * 16 + (lane >> 4) * 4;
     if (row >= M || col >= N) continue;
     float* c = C + (int64_t)row * ldc + col;
+    f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int z = 0; z < ksplit; ++z) s += *reinterpret_cast<const f32x4*>(ws + ((int64_t)z * tiles + tile) * (GB * GB) + (int64_t)r * 4);
+    *reinterpret_cast<f32x4*>(c) = s;
+  }
+}
+
+// the same over the tiles of a batched launch: tile t belongs to matrix t / tiles_per_mat
+__global__ __launch_bounds__(256) void splitk_reduce_frag_batched_kernel(const float* __restrict__ ws, BatchPtrs bp, int tiles_per_mat, int M,
+                                                                         int N, int64_t ldc, int ksplit, int tiles, int tiles_n,
+                                                                         int accumulate) {
+  const int64_t total = (int64_t)tiles * (GB * GB / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int tile = (int)(i >> 14), r = (int)(i & 16383);
+    const int b = tile / tiles_per_mat, local = tile - b * tiles_per_mat;
+    const int lane = r & 63, frag = (r >> 6) & 31, wave = r >> 11;
+    const int fj = frag >> 3, fi = frag & 7, wm = wave >> 2, wn = wave & 3;
+    const int row = (local / tiles_n) * GB + wm * 128 + fi * 16 + (lane & 15);
+    const int col = (local % tiles_n) * GB + wn * 64 + fj * 16 + (lane >> 4) * 4;
+    if (row >= M || col >= N) continue;
+    float* c = reinterpret_cast<float*>(bp.C[b]) + (int64_t)row * ldc + col;
     f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int z = 0; z < ksplit; ++z) s += *reinterpret_cast<const f32x4*>(ws + ((int64_t)z * tiles + tile) * (GB * GB) + (int64_t)r * 4);
@@ -1471,7 +1510,7 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
                     (cv || ((int64_t)(trans_a ? K : M) * lda) < (1ll << 30)) && (((int64_t)(trans_b ? K : N) * ldb) < (1ll << 30));   // (cv: A's extent is the activation's, checked by the caller)
   if (fast) {
     GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, accumulate, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, nullptr, nullptr,
-                 0, 0, 0, 0, 0, 0, 0, 0, 0, colstats, 0};
+                 0, 0, 0, 0, 0, 0, 0, 0, 0, colstats, 0, 0};
     if (cv) { p.cv_C = cv->C; p.cv_logC = cv->logC; p.cv_Hp = cv->Hp; p.cv_Wp = cv->Wp; p.cv_Ho = cv->Ho; p.cv_Wo = cv->Wo; p.cv_kw = cv->kw; p.cv_inv_kw = (65536 + cv->kw - 1) / cv->kw; p.cv_stride = cv->stride; p.cv_logP = cv->logP; }
     // bytes addressable through each operand: (rows - 1) * ld + contiguous extent
     p.a_bytes = cv ? (unsigned)cv->in_bytes : (unsigned)((((int64_t)(trans_a ? K : M) - 1) * lda + (trans_a ? M : K)) * 2);
@@ -1622,7 +1661,7 @@ extern "C" int fcmf_gemm_fp8(fcmf_gemm_ctx* ctx, const void* A, const float* sa,
       (int64_t)N * ldb >= (1ll << 31) || M < 256 || N < 256)
     return FCMF_ERR_UNSUPPORTED;
   const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
-  GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, 0, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, sa, sb, 0, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, 0};
+  GemmParams p{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, epilogue, 0, 1, 0, 0, 0, 0, colsum, 0, 0, nullptr, 0, sa, sb, 0, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, 0};
   p.a_bytes = (unsigned)(((int64_t)M - 1) * lda + K);
   p.b_bytes = (unsigned)(((int64_t)N - 1) * ldb + K);
   p.c_bytes = (unsigned)c_extent;
@@ -1742,6 +1781,80 @@ extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void*
                          int out_dtype, int epilogue, int accumulate, void* stream) {
   return gemm_impl(ctx, A, B, C, bias, aux, colsum, M, N, K, lda, ldb, ldc, trans_a, trans_b, in_dtype, out_dtype, epilogue,
                    accumulate, stream, nullptr);
+}
+
+// ---- batched weight gradients -----------------------------------------------------------------------------------------
+// C_i [M, N] float32 (+)= A_i^T B_i for `count` same-shape problems (A_i = dY_i [K, M], B_i = X_i [K, N], bf16, K = tokens): the
+// weight gradients of the layers of an encoder, queued during the backward pass and multiplied together.  Chunks of up to
+// BATCH_MAX matrices form one work list of (matrix, tile, k-split) items for the persistent 256 x 256 kernel; the split factor
+// is chosen for whole rounds of the chip (a 768 x 768 gradient alone is 9 tiles: alone it needed a 28-way split and a 64 MB
+// partial-tile round trip).  Shapes the persistent kernel does not take, and count == 1, run as `count` fcmf_gemm calls.
+extern "C" int fcmf_gemm_dw_batched(fcmf_gemm_ctx* ctx, int count, const void* const* A, const void* const* B, void* const* C, int M, int N,
+                                    int K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate, void* stream) {
+  if (count < 0 || !A || !B || !C || M < 0 || N < 0 || K < 0) return FCMF_ERR_ARG;
+  for (int i = 0; i < count; ++i)
+    if (!A[i] || !B[i] || !C[i]) return FCMF_ERR_ARG;
+  if (count == 0 || M == 0 || N == 0) return FCMF_OK;
+  const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  bool ok = count > 1 && cfg.force_tile != 128 && K > 0 && M >= 256 && N >= 256 && lda % 8 == 0 && ldb % 8 == 0 && M % 8 == 0 && N % 8 == 0 &&
+            ldc % 8 == 0 && (int64_t)K * lda < (1ll << 30) && (int64_t)K * ldb < (1ll << 30);
+  for (int i = 0; ok && i < count; ++i) ok = al16(A[i]) && al16(B[i]) && al16(C[i]);
+  if (!ok) {
+    for (int i = 0; i < count; ++i) {
+      const int rc = gemm_impl(ctx, A[i], B[i], C[i], nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, 1, 1, FCMF_BF16, FCMF_F32, FCMF_EPI_NONE,
+                               accumulate, stream, nullptr);
+      if (rc != FCMF_OK) return rc;
+    }
+    return FCMF_OK;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int slots = cfg.num_cus, tpm = ((M + GB - 1) / GB) * ((N + GB - 1) / GB), nk = (K + 31) / 32;
+  const int chunks = (count + BATCH_MAX - 1) / BATCH_MAX;
+  const size_t smem = (size_t)RING_BYTES + 8 * 4096;
+  auto kern = gemm_bf16_dw_batched_kernel;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  for (int c = 0, first = 0; c < chunks; ++c) {
+    const int n = (count - first + (chunks - c) - 1) / (chunks - c);          // near-equal chunks
+    BatchPtrs bp{};
+    for (int i = 0; i < n; ++i) { bp.A[i] = A[first + i]; bp.B[i] = B[first + i]; bp.C[i] = C[first + i]; }
+    const int tiles = n * tpm;
+    // k-split for whole rounds: the smallest split whose last round is at least 92 % full (else the fullest), each split at least
+    // 8 k-tiles deep, partial tiles within the context's workspace
+    int best = 1;
+    double best_eff = 0.0;
+    const int64_t ws_tiles = cfg.ws ? cfg.ws_bytes / ((int64_t)GB * GB * 4) : 0;
+    for (int sp = 1; sp <= 16; ++sp) {
+      if (sp > 1 && ((int64_t)sp * tiles > ws_tiles || nk / sp < 8)) break;
+      const int64_t items = (int64_t)tiles * sp, rounds = (items + slots - 1) / slots;
+      const double eff = (double)items / (double)(rounds * slots);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+      if (eff >= 0.92) { best = sp; break; }
+    }
+    GemmParams p{};
+    p.A = bp.A[0]; p.B = bp.B[0]; p.C = bp.C[0];
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.epilogue = FCMF_EPI_NONE; p.accumulate = accumulate;
+    p.a_bytes = (unsigned)((((int64_t)K - 1) * lda + M) * 2);
+    p.b_bytes = (unsigned)((((int64_t)K - 1) * ldb + N) * 2);
+    p.ktiles_per_split = (nk + best - 1) / best;
+    p.ksplit = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    p.tiles = tiles; p.tiles_per_mat = tpm;
+    p.total_items = tiles * p.ksplit;
+    p.ws = p.ksplit > 1 ? cfg.ws : nullptr;
+    const dim3 grid(p.total_items < slots ? p.total_items : slots);
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, p, bp);
+    if (p.ws) {
+      const int64_t total4 = (int64_t)tiles * (GB * GB / 4);
+      const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+      hipLaunchKernelGGL(splitk_reduce_frag_batched_kernel, dim3(blocks), dim3(256), 0, st, p.ws, bp, tpm, M, N, ldc, p.ksplit, tiles,
+                         (N + GB - 1) / GB, accumulate);
+    }
+    FCMF_CHECK_LAUNCH();
+    first += n;
+  }
+  if (ctx) snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm_bf16_dw_batched_kernel");
+  return FCMF_OK;
 }
 
 // Implicit-GEMM convolution on the MFMA GEMM kernels: y[(n, oy, ox), co] = sum_{ky, kx, c} x[n, oy s + ky, ox s + kx, c] w[co, (ky, kx, c)].

@@ -89,6 +89,7 @@ SIGNATURES = {
     "fcmf_bn_apply": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _vp],
     "fcmf_bn_apply_pad": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _vp],
     "fcmf_conv_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_gemm_dw_batched": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _vp],
     "fcmf_conv_gemm_runs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_pack_rgb0": [_vp, _i, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
     "fcmf_gemm_colstats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp],
@@ -162,7 +163,7 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda id
 
 
 # ---- GEMM contexts: one per (device, stream), created on first use ---------------------------------------------------------
-SPLITK_WORKSPACE_BYTES = 96 << 20   # >= ksplit*M*N*4 of every weight-gradient GEMM of FCMF-base (66 MB for 768x768 x 28 splits)
+SPLITK_WORKSPACE_BYTES = 512 << 20   # >= ksplit*M*N*4 of every weight-gradient GEMM of FCMF-base (66 MB for 768x768 x 28 splits)
 _gemm_ctx = {}
 _gemm_tuning = dict(tile=int(os.environ.get("FCMF_GEMM_TILE", "0")), kb=32 if os.environ.get("FCMF_GEMM_KB") == "32" else 64,
                     cus=int(os.environ.get("FCMF_GEMM_CUS", "256")), nt_min_mb=int(os.environ.get("FCMF_GEMM_NT_MIN_MB", "0")))

@@ -246,6 +246,8 @@ class GradReducer:
         self._launched[bi] = True
         self.launch_log.append(bi)
         lo, hi, ps = self.buckets[bi]
+        from . import ops
+        ops.flush_deferred_dw()               # queued weight-gradient GEMMs of this bucket's parameters are issued before it is sent
         for p in ps:                          # gradients that arrived while disabled (accumulation) or not at all
             self.arena.adopt(p)
         buf = self.arena.flat[lo:hi]

@@ -6,7 +6,9 @@ Activations are float32 (parity mode) or bfloat16 (throughput mode); master para
 their gradients are always float32.  bf16 copies of the weights ("shadows") are cached and
 refreshed when the parameter changes.
 """
+import ctypes
 import math
+import os
 import weakref
 
 import torch
@@ -250,6 +252,8 @@ _grad_arena = None
 def set_grad_arena(arena):
     global _grad_arena
     _grad_arena = arena
+    if arena is not None and deferred_dw.reset not in arena.on_zero:
+        arena.on_zero.append(deferred_dw.reset)      # a step that died inside backward() must not leave its queue to the next one
 
 
 def grad_arena():
@@ -341,8 +345,86 @@ def gemm_trace_end():
     return [(name, fl, e0.elapsed_time(e1)) for name, fl, e0, e1 in tr]
 
 
+# ---- deferred weight gradients -------------------------------------------------------------------------------------------
+# dW = dY^T X of an nn.Linear is needed only once the backward pass is over (grad clipping, the optimizer, the gradient
+# exchange of its bucket), and one layer's dW is a handful of 256 x 256 tiles: alone it fills the chip only through a deep
+# split of K plus a reduce pass per matrix.  During loss.backward() the weight-gradient GEMMs whose destination is a slice of the
+# step's gradient arena are therefore QUEUED (operands kept alive) and multiplied together, all same-shape matrices of a group in
+# one fcmf_gemm_dw_batched launch: at the end of the backward pass (an autograd-engine callback), before a data-parallel bucket that
+# contains queued gradients is sent (dp.GradReducer), before anything else reads the arena (flush_deferred_dw), or when the queue
+# holds more than DEFER_DW_MAX_BYTES of operands.  Gradients into temporaries (a second use of a shared weight: autograd ADDS the
+# temporary right away) are never queued.
+DEFER_DW = os.environ.get("FCMF_DEFER_DW", "1") == "1"
+DEFER_DW_MAX_BYTES = 48 << 30
+
+
+class _DeferredDW:
+    def __init__(self):
+        self.q, self.bytes, self.armed = [], 0, False
+        self.batched_launches = self.batched_matrices = 0
+
+    def reset(self):
+        self.q, self.bytes, self.armed = [], 0, False
+
+    def wanted(self, A, B, C, ta, tb, bias, aux, epi, colsum):
+        if not (DEFER_DW and ta and tb and bias is None and aux is None and colsum is None and epi == H.EPI_NONE
+                and C.dtype == torch.float32 and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16):
+            return False
+        arena = _grad_arena
+        return (arena is not None and C.device == arena.flat.device
+                and C.untyped_storage().data_ptr() == arena.flat.untyped_storage().data_ptr())
+
+    def push(self, A, B, C, M, N, K, lda, ldb, ldc, acc):
+        if not self.armed:
+            try:      # (only legal while the autograd engine runs: outside of backward() the GEMM runs right away)
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            except RuntimeError:
+                return False
+            self.armed = True
+        self.q.append((A, B, C, M, N, K, lda, ldb, ldc, bool(acc)))
+        self.bytes += A.numel() * A.element_size() + B.numel() * B.element_size()
+        if self.bytes > DEFER_DW_MAX_BYTES:
+            self.flush(final=False)
+        return True
+
+    def flush(self, final=True):
+        q, self.q, self.bytes = self.q, [], 0
+        if final:
+            self.armed = False
+        groups = {}
+        for e in q:
+            groups.setdefault((e[0].device,) + e[3:], []).append(e)
+        for key, es in groups.items():
+            _, M, N, K, lda, ldb, ldc, acc = key
+            H.require_cuda(es[0][0])
+            with torch.cuda.device(key[0]):
+                ctx = H.gemm_ctx(workspace=True)
+                arr = lambda i: (ctypes.c_void_p * len(es))(*[e[i].data_ptr() for e in es])
+                if _gemm_trace is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                H.check(H.lib().fcmf_gemm_dw_batched(ctx, len(es), arr(0), arr(1), arr(2), M, N, K, lda, ldb, ldc, int(acc), H.stream()),
+                        "fcmf_gemm_dw_batched")
+                if _gemm_trace is not None:
+                    e1.record()
+                    _gemm_trace.append((H.lib().fcmf_gemm_ctx_last_kernel(ctx).decode(), 2.0 * M * N * K * len(es), e0, e1))
+            self.batched_launches += 1
+            self.batched_matrices += len(es)
+
+
+deferred_dw = _DeferredDW()
+
+
+def flush_deferred_dw():
+    """multiply the queued weight gradients now (anything that reads the gradient arena before backward() has returned)"""
+    if deferred_dw.q:
+        deferred_dw.flush(final=False)
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI_NONE, acc=False, colsum=None):
     H.require_cuda(A, B, C)
+    if deferred_dw.wanted(A, B, C, ta, tb, bias, aux, epi, colsum) and deferred_dw.push(A, B, C, M, N, K, lda, ldb, ldc, acc):
+        return
     ctx = H.gemm_ctx(workspace=acc or C.dtype == torch.float32)   # (weight-gradient GEMMs: the context owns the split-K scratch of this stream)
     if _gemm_trace is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1092,3 +1092,36 @@ def test_layernorm_emits_the_fp8_copy_its_consumer_needs(dev, p):
     q, sc = outs[1][5]
     q2, sc2 = ops.quant_fp8_rows(outs[1][1], rows, Hd, Hd)
     assert torch.equal(q, q2) and torch.equal(sc, sc2)
+
+
+@pytest.mark.parametrize("count,N,K,Mtok,acc", [(12, 768, 768, 8200, 1), (40, 256, 512, 1024, 0), (3, 776, 520, 4096, 1), (5, 128, 768, 2048, 1),
+                                                (1, 768, 768, 4096, 1), (7, 3072, 768, 2048, 0)])
+def test_gemm_dw_batched_matches_separate_weight_gradients(dev, count, N, K, Mtok, acc):
+    """fcmf_gemm_dw_batched (the tiles of `count` same-shape weight gradients as ONE work list of the persistent kernel, k-split
+    chosen for whole rounds, batched reduce pass) against `count` fcmf_gemm calls and the float64 product: 12 encoder-layer
+    gradients with a ragged token count, 40 matrices (two chunks of the 32-entry pointer table), ragged tiles, a shape the
+    persistent kernel refuses (falls back to separate GEMMs inside the library), count = 1, accumulate on / off (NaN-poisoned
+    outputs when off)."""
+    import ctypes
+    ops, H = _ops()
+    dYs = [_rand((Mtok, N), dev, torch.bfloat16, seed=10 + i) for i in range(count)]
+    Xs = [_rand((Mtok, K), dev, torch.bfloat16, seed=100 + i) for i in range(count)]
+    init = lambda i: (_rand((N, K), dev, seed=200 + i) if acc else torch.full((N, K), float("nan"), device=dev))
+    got = [init(i) for i in range(count)]
+    want = [init(i) for i in range(count)]
+    arr = lambda ts: (ctypes.c_void_p * count)(*[t.data_ptr() for t in ts])
+    ctx = H.gemm_ctx(workspace=True)
+    H.check(H.lib().fcmf_gemm_dw_batched(ctx, count, arr(dYs), arr(Xs), arr(got), N, K, Mtok, N, K, K, acc, H.stream()), "fcmf_gemm_dw_batched")
+    name = H.last_gemm_kernel()
+    for i in range(count):
+        ops.gemm(dYs[i], Xs[i], want[i], N, K, Mtok, N, K, K, 1, 1, acc=bool(acc))
+    if count > 1 and N >= 256 and K >= 256:
+        assert name == "gemm_bf16_dw_batched_kernel", name
+    for i in (0, count // 2, count - 1):
+        ref = dYs[i].double().cpu().t() @ Xs[i].double().cpu()
+        if acc:
+            ref = ref + _rand((N, K), dev, seed=200 + i).double().cpu()
+        assert torch.isfinite(got[i]).all()
+        assert rel_err(got[i], ref) < 2e-3 and rel_err(got[i], want[i]) < 1e-5, i
+    two = (ctypes.c_void_p * 2)(dYs[0].data_ptr(), dYs[0].data_ptr())
+    assert H.lib().fcmf_gemm_dw_batched(ctx, 2, two, None, None, N, K, Mtok, N, K, K, acc, H.stream()) == -1        # missing pointer tables

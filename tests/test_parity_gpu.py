@@ -835,3 +835,49 @@ def test_iaog_config3_full_size_bf16(dev):
     finally:
         _set(torch.float32)
         model.zero_grad(set_to_none=True)
+
+
+def test_deferred_weight_gradients_equal_immediate_ones_bf16(base, dev):
+    """ops.deferred_dw: with a gradient arena active, the weight-gradient GEMMs of loss.backward() are queued and multiplied
+    together at the end of the backward pass (fcmf_gemm_dw_batched; the engine's final callback).  FCMF-base on the fixture batch,
+    bf16: the arena after backward() equals the arena of the same step with the queue switched off to split-K rounding (1e-5 of
+    every parameter's gradient norm), the queue is empty when backward() returns, the batched entry point really ran, and a
+    flush in the middle of the queue's life (what a data-parallel bucket does) changes nothing."""
+    from fcmf_framework import ops
+    from fcmf_framework.dp import GradArena
+    z, model, batch = base
+    b = batch_to(batch, dev)
+    old_arena = ops.grad_arena()
+    try:
+        _set(torch.bfloat16)
+        arena = GradArena.for_model(model)
+        flats = {}
+        for mode in ("off", "on", "on+early-flush"):
+            ops.DEFER_DW = mode != "off"
+            arena.zero()
+            before = ops.deferred_dw.batched_matrices
+            loss = model.loss_aspects(_run_aspects(model, b), b["labels"])
+            if mode == "on+early-flush":
+                # the first parameter whose gradient arrives flushes what is queued so far (GradReducer._launch does this per bucket)
+                hooks = [p.register_post_accumulate_grad_hook(lambda p: ops.flush_deferred_dw()) for p in list(model.parameters())[-40::7]]
+            loss.backward()
+            if mode == "on+early-flush":
+                for h in hooks:
+                    h.remove()
+            assert not ops.deferred_dw.q and not ops.deferred_dw.armed
+            assert (ops.deferred_dw.batched_matrices > before) == (mode != "off")
+            flats[mode] = arena.flat.clone()
+        ref = flats["off"]
+        assert torch.isfinite(ref).all() and ref.abs().max() > 0
+        for mode in ("on", "on+early-flush"):
+            for p in arena.order:
+                lo = arena.offset[id(p)]
+                a, r = flats[mode][lo:lo + p.numel()], ref[lo:lo + p.numel()]
+                assert (a - r).norm() <= 1e-5 * r.norm() + 1e-12, mode
+    finally:
+        ops.DEFER_DW = True
+        if "arena" in locals():
+            arena.deactivate()
+        ops.set_grad_arena(old_arena)
+        _set(torch.float32)
+        model.zero_grad(set_to_none=True)

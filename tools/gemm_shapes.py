@@ -22,7 +22,7 @@ ops.gemm = gemm
 for m in list(sys.modules.values()):
     if getattr(m, "__name__", "").startswith("fcmf_framework") and getattr(m, "ops", None) is ops:
         pass
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+sys.argv = ["bench.py"] + sys.argv[1:] + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
 bench.main()
 for k, n in sorted(seen.items(), key=lambda kv: (kv[0][0], -kv[0][1] * kv[0][2] * kv[0][3])):
     print("GEMM %-44s M=%6d N=%5d K=%6d ta=%d tb=%d acc=%d  x%d" % (*k, n), file=sys.stderr)
