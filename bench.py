@@ -246,24 +246,28 @@ def run_fcmf(args, rank, world, dev, large=False):
     # host -> HBM: (1) the bare copy of one batch from pinned memory; (2) the step loop fed through the drivers' DevicePrefetcher --
     # every step consumes a FRESH host batch (pinned producer buffers, copy stream, one batch ahead): `value_with_h2d` is that
     # loop's rate.  Never part of `value` (inputs are resident before ITS timed region).
-    from device_prefetch import DevicePrefetcher
-    pinned = {k: v.pin_memory() for k, v in host.items()}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        tmp = {k: v.to(dev, non_blocking=True) for k, v in pinned.items()}
-    torch.cuda.synchronize()
-    h2d_ms = (time.perf_counter() - t0) / 3 * 1e3
-    del tmp
+    # (single-GPU runs only: with more ranks every step is a collective, and the other ranks have left by now -- the 2-rank
+    #  rehearsal of round 3 caught rank 0 waiting for them here)
+    h2d_ms = ms_step_pf = None
     n_pf = max(3, min(args.steps, 8))
-    pf = iter(DevicePrefetcher((pinned for _ in range(n_pf + 1)), dev))
-    step(next(pf))                                   # (pipeline fill: the first copy is exposed by construction)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for b in pf:
-        step(b)
-    torch.cuda.synchronize()
-    ms_step_pf = (time.perf_counter() - t0) / n_pf * 1e3
+    if world == 1:
+        from device_prefetch import DevicePrefetcher
+        pinned = {k: v.pin_memory() for k, v in host.items()}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tmp = {k: v.to(dev, non_blocking=True) for k, v in pinned.items()}
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t0) / 3 * 1e3
+        del tmp
+        pf = iter(DevicePrefetcher((pinned for _ in range(n_pf + 1)), dev))
+        step(next(pf))                                   # (pipeline fill: the first copy is exposed by construction)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in pf:
+            step(b)
+        torch.cuda.synchronize()
+        ms_step_pf = (time.perf_counter() - t0) / n_pf * 1e3
     ms_step = dt / args.steps * 1e3
     out = {
         "metric": f"train samples/sec (fwd+bwd+step) FCMF-large seq256x100ROI ({args.dtype}; BASELINE configs[4])"
@@ -281,10 +285,11 @@ def run_fcmf(args, rank, world, dev, large=False):
                    "sample_unit": "1 review = 6 aspect forwards",
                    "dense_flops_per_sample_fwd_bwd": algorithmic_flops_per_sample(CFG, S, NI, 49, NR, A)},
         "loss": round(float(loss.item()), 4),
-        "h2d_ms_per_batch": round(h2d_ms, 2),
-        "value_with_h2d": round(world * B / (ms_step_pf * 1e-3), 2),
-        "ms_per_step_with_h2d": round(ms_step_pf, 2),
-        "h2d": f"{n_pf} steps, each on a fresh pinned host batch through device_prefetch.DevicePrefetcher (copy stream, one batch ahead)",
+        "h2d_ms_per_batch": None if h2d_ms is None else round(h2d_ms, 2),
+        "value_with_h2d": None if ms_step_pf is None else round(world * B / (ms_step_pf * 1e-3), 2),
+        "ms_per_step_with_h2d": None if ms_step_pf is None else round(ms_step_pf, 2),
+        "h2d": (f"{n_pf} steps, each on a fresh pinned host batch through device_prefetch.DevicePrefetcher (copy stream, one batch ahead)"
+                if world == 1 else "measured on single-GPU runs only"),
         "roofline": gemm_roofline(trace),
     }
     if comm is not None:
