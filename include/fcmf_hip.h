@@ -385,9 +385,10 @@ int fcmf_gemm_dw_batched(fcmf_gemm_ctx* ctx, int count, const void* const* A, co
  * `pix` elements per pixel (a power of two: 4 = RGB0, written by fcmf_pack_rgb0) and its zero border; for every kernel row ky the
  * contraction walks ONE contiguous run of `run` elements (a power of two >= 32, >= kw * pix: 32 = 8 pixels for kw = 7) starting at
  * pixel (oy*stride + ky, ox*stride).  K = kh * run; w [Cout, kh * run] bf16 holds zeros where the run exceeds the kernel (kx >= kw,
- * the padding channel).  stride * pix must be a multiple of 8 (16-byte DMA).  y [n*Ho*Wo, Cout] bf16. */
-int fcmf_conv_gemm_runs(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int pix, int run, int Ho,
-                        int Wo, int kh, int stride, int Cout, void* stream);
+ * the padding channel).  stride * pix must be a multiple of 8 (16-byte DMA).  y [n*Ho*Wo, Cout] bf16.  stats (optional, may be
+ * NULL): the block statistics of y as fcmf_gemm_colstats writes them (same restriction: FCMF_ERR_UNSUPPORTED for Cout < 256). */
+int fcmf_conv_gemm_runs(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, float* stats, int n, int Hp, int Wp, int pix, int run,
+                        int Ho, int Wo, int kh, int stride, int Cout, void* stream);
 /* crops in any layout (element strides of n, h, w, c; float32 / float64 / bf16; 3 channels) -> the interior of dst
  * [N, H + 2 pad, Wp, 4] bf16, Wp >= W + 2 pad (channel 3 = 0; the border is NOT written: zero it once) */
 int fcmf_pack_rgb0(const void* src, int src_dtype, void* dst, int N, int H, int W, int64_t sn, int64_t sh, int64_t sw, int64_t sc,

@@ -1534,6 +1534,8 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
     if (cfg.force_tile == 128) large = false;
     if (cfg.force_tile == 256 || cfg.force_tile == 192) large = tile_ok;
     if (colstats) {       // block statistics exist in the 256-row bf16 kernels only: the caller falls back to a statistics pass
+      // (they were built into the 128 x 128 kernel too -- the trunk's 64 / 128-channel layers -- and measured: its epilogue, a
+      //  fragment-layout one, pays as much for the rounding, the 128 shuffles and two barriers as the separate pass costs)
       if (!(tile_ok && M >= 256 && N >= 256 && out_dtype == FCMF_BF16 && !trans_a && !trans_b && epilogue == FCMF_EPI_NONE &&
             !accumulate && !aux))
         return FCMF_ERR_UNSUPPORTED;
@@ -1906,8 +1908,8 @@ extern "C" int fcmf_conv_gemm_colstats(fcmf_gemm_ctx* ctx, const void* x, const 
 // e.g. 8 pixels x 4 = 32 for kw = 7) that starts at pixel (oy * stride + ky, ox * stride): K = kh * run, w [Cout, kh * run] with
 // zeros where the run exceeds the kernel (kx >= kw, or the padding channel).  Same kernels as fcmf_conv_gemm: the tap offset is
 // ky rows of the input, the per-lane offset the run's first pixel.
-extern "C" int fcmf_conv_gemm_runs(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int pix, int run,
-                                   int Ho, int Wo, int kh, int stride, int Cout, void* stream) {
+extern "C" int fcmf_conv_gemm_runs(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, float* stats, int n, int Hp, int Wp, int pix,
+                                   int run, int Ho, int Wo, int kh, int stride, int Cout, void* stream) {
   if (!x || !w || !y || n <= 0 || Hp <= 0 || Wp <= 0 || pix <= 0 || run <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || stride <= 0 || Cout <= 0)
     return FCMF_ERR_ARG;
   if ((pix & (pix - 1)) || (run & (run - 1)) || run < 32 || run % pix || kh > 64 || (stride * pix) % 8) return FCMF_ERR_UNSUPPORTED;
@@ -1923,7 +1925,7 @@ extern "C" int fcmf_conv_gemm_runs(fcmf_gemm_ctx* ctx, const void* x, const void
   const ConvGeom cv{run, logC, Hp, Wp, Ho, Wo, 1, stride, in_elems * 2, logP};
   const int K = kh * run;
   return gemm_impl(ctx, x, w, y, nullptr, nullptr, nullptr, (int)M, Cout, K, K, K, Cout, 0, 0, FCMF_BF16, FCMF_BF16, FCMF_EPI_NONE, 0,
-                   stream, &cv);
+                   stream, &cv, stats);
 }
 
 extern "C" int fcmf_colsum(const void* X, float* out, int M, int N, int64_t ldx, int dtype, int accumulate,

@@ -90,7 +90,7 @@ SIGNATURES = {
     "fcmf_bn_apply_pad": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _vp],
     "fcmf_conv_gemm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_gemm_dw_batched": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _vp],
-    "fcmf_conv_gemm_runs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fcmf_conv_gemm_runs": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fcmf_pack_rgb0": [_vp, _i, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
     "fcmf_gemm_colstats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp],
     "fcmf_conv_gemm_colstats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

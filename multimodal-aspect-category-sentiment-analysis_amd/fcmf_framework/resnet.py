@@ -122,7 +122,7 @@ def _stem_runs_ok(conv, x, dt):
             and conv.stride[0] == 2 and x.dtype in (torch.float32, torch.float64, torch.bfloat16))
 
 
-def conv2d_stem(v, conv):
+def conv2d_stem(v, conv, stats=False):
     """the stem (conv1: k x k, k <= 8, stride 2, 3 input channels) without a patch matrix: v = the crops as a strided NHWC view
     [N, H, W, 3] of any float dtype.  fcmf_pack_rgb0 writes them as bf16 RGB0 pixels into a zero-bordered buffer, and
     fcmf_conv_gemm_runs contracts, per kernel row, one 32-element run (8 pixels x 4) of it against w [Cout, kh, 8, 4] (zeros for
@@ -146,9 +146,11 @@ def conv2d_stem(v, conv):
         return ops.cast(w.view(Cout, k * 32).contiguous(), torch.bfloat16)
     wm = ops.shadows.derived(conv.weight, ("stem_runs", torch.bfloat16), build)
     y = torch.empty((N * Ho * Wo, Cout), dtype=torch.bfloat16, device=v.device)
-    H.check(H.lib().fcmf_conv_gemm_runs(H.gemm_ctx(), H.ptr(buf), H.ptr(wm), H.ptr(y), N, Hh + 2 * pad, Wp, 4, 32, Ho, Wo, k, 2, Cout,
-                                        H.stream()), "fcmf_conv_gemm_runs")
-    return y.view(N, Ho, Wo, Cout)
+    blocks = _block_stats(N * Ho * Wo, Cout, torch.bfloat16, v.device) if stats else None
+    H.check(H.lib().fcmf_conv_gemm_runs(H.gemm_ctx(), H.ptr(buf), H.ptr(wm), H.ptr(y), H.ptr(blocks), N, Hh + 2 * pad, Wp, 4, 32, Ho, Wo, k, 2,
+                                        Cout, H.stream()), "fcmf_conv_gemm_runs")
+    y = y.view(N, Ho, Wo, Cout)
+    return (y, blocks) if stats else y
 
 
 def conv2d_nhwc(x, conv, src_strides=None, stats=False):
@@ -583,18 +585,18 @@ class ResNet(nn.Module):
         xs = x if x.dtype in (torch.float32, torch.bfloat16) else x.float()
         v = xs.permute(0, 2, 3, 1)                                       # strided NHWC view of the NCHW crops
         if tape is None and _stem_runs_ok(self.conv1, v, ops.compute_dtype()):
-            y = conv2d_stem(v, self.conv1)
+            y, blk = conv2d_stem(v, self.conv1, stats=True)
         else:
-            y = conv2d_nhwc(v, self.conv1, src_strides=v.stride())
+            y, blk = conv2d_nhwc(v, self.conv1, src_strides=v.stride(), stats=True)
         if tape is None:
-            y = batchnorm_nhwc_(y, self.bn1, groups, relu=True)
+            y = batchnorm_nhwc_(y, self.bn1, groups, relu=True, blocks=blk)
             y = maxpool3x3s2_nhwc(y)
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for blk in layer:
                     y = blk.forward_nhwc(y, groups)
             return y
         stem = {"v": v, "y": y, "s": {}}
-        stem["z"] = batchnorm_nhwc_(y, self.bn1, groups, relu=True, out=torch.empty_like(y), save=stem["s"])
+        stem["z"] = batchnorm_nhwc_(y, self.bn1, groups, relu=True, out=torch.empty_like(y), save=stem["s"], blocks=blk)
         tape.append(stem)
         y = maxpool3x3s2_nhwc(stem["z"])
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):

@@ -399,7 +399,8 @@ def test_stem_convolution_without_patch_matrix(dev, N, hw, src):
         v = x.permute(0, 2, 3, 1)
         with torch.no_grad():
             assert R._stem_runs_ok(conv, v, ops.compute_dtype())
-            y_runs = R.conv2d_stem(v, conv)
+            y_runs, blk = R.conv2d_stem(v, conv, stats=True)
+            assert blk is None                                  # (64 output channels: the statistics pass stays)
             ve = v if src != torch.float64 else x.float().permute(0, 2, 3, 1)   # (the patch-matrix kernel takes float32 / bf16 crops)
             y_exp = R.conv2d_nhwc(ve, conv, src_strides=ve.stride())
         assert y_runs.shape == y_exp.shape
