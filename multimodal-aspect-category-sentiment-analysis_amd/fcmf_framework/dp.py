@@ -59,6 +59,8 @@ class GradArena:
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.view = {id(p): self.flat[self.offset[id(p)]:self.offset[id(p)] + p.numel()].view_as(p) for p in order}
         self._by_ptr = {p.data_ptr(): p for p in order}
+        self._slice_param = {self.view[id(p)].data_ptr(): p for p in order}     # arena address -> the parameter whose slice starts there
+        self.fwd_uses = {}                    # parameter address -> forward GEMMs that used it since zero() (ops.gemm_nt)
         self._taken = set()
         self.on_zero = []                     # callbacks (the reducer resets its bucket state here)
         self.activate()
@@ -92,10 +94,21 @@ class GradArena:
         step, not per micro-step.)"""
         self.flat.zero_()
         self._taken.clear()
+        self.fwd_uses.clear()
         for p in self.order:
             p.grad = None
         for cb in self.on_zero:
             cb()
+
+    def note_forward(self, ptr):
+        self.fwd_uses[ptr] = self.fwd_uses.get(ptr, 0) + 1
+
+    def used_once(self, slice_ptr):
+        """True if the arena slice starting at `slice_ptr` belongs to a parameter that exactly ONE forward GEMM has used since
+        zero(): its weight gradient then has a single producer in this backward pass (ops.deferred_dw may delay it; with two
+        producers autograd ADDS their results the moment each Function returns)"""
+        p = self._slice_param.get(slice_ptr)
+        return p is not None and self.fwd_uses.get(p.data_ptr(), 0) == 1
 
     def take(self, param):
         """the slice of `param` if nothing has claimed it in this step (else None: the caller uses a temporary and

@@ -352,8 +352,10 @@ def gemm_trace_end():
 # step's gradient arena are therefore QUEUED (operands kept alive) and multiplied together, all same-shape matrices of a group in
 # one fcmf_gemm_dw_batched launch: at the end of the backward pass (an autograd-engine callback), before a data-parallel bucket that
 # contains queued gradients is sent (dp.GradReducer), before anything else reads the arena (flush_deferred_dw), or when the queue
-# holds more than DEFER_DW_MAX_BYTES of operands.  Gradients into temporaries (a second use of a shared weight: autograd ADDS the
-# temporary right away) are never queued.
+# holds more than DEFER_DW_MAX_BYTES of operands.  Only parameters with exactly ONE forward use in the step qualify (the arena
+# counts them in gemm_nt): a weight applied twice has two gradient producers whose results autograd adds the moment each
+# Function returns.  The destination is remembered by address, never by tensor: autograd must stay the only holder of the
+# returned slice, or AccumulateGrad clones it -- unwritten -- instead of adopting it as p.grad.
 DEFER_DW = os.environ.get("FCMF_DEFER_DW", "1") == "1"
 DEFER_DW_MAX_BYTES = 48 << 30
 
@@ -371,8 +373,11 @@ class _DeferredDW:
                 and C.dtype == torch.float32 and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16):
             return False
         arena = _grad_arena
+        # ... into a slice of the arena that belongs to a parameter with ONE use in this step's forward (a weight that is applied
+        # twice -- the fusion layer runs 7 + 1 times -- has two gradient producers, and autograd adds their results as soon as
+        # each Function returns: neither may be late)
         return (arena is not None and C.device == arena.flat.device
-                and C.untyped_storage().data_ptr() == arena.flat.untyped_storage().data_ptr())
+                and C.untyped_storage().data_ptr() == arena.flat.untyped_storage().data_ptr() and arena.used_once(C.data_ptr()))
 
     def push(self, A, B, C, M, N, K, lda, ldb, ldc, acc):
         if not self.armed:
@@ -381,7 +386,9 @@ class _DeferredDW:
             except RuntimeError:
                 return False
             self.armed = True
-        self.q.append((A, B, C, M, N, K, lda, ldb, ldc, bool(acc)))
+        # (the destination is remembered by ADDRESS: the arena owns that memory, and a second reference to the tensor object would
+        #  make autograd's AccumulateGrad clone the -- not yet written -- slice instead of adopting it as p.grad)
+        self.q.append((A, B, C.data_ptr(), M, N, K, lda, ldb, ldc, bool(acc)))
         self.bytes += A.numel() * A.element_size() + B.numel() * B.element_size()
         if self.bytes > DEFER_DW_MAX_BYTES:
             self.flush(final=False)
@@ -399,7 +406,7 @@ class _DeferredDW:
             H.require_cuda(es[0][0])
             with torch.cuda.device(key[0]):
                 ctx = H.gemm_ctx(workspace=True)
-                arr = lambda i: (ctypes.c_void_p * len(es))(*[e[i].data_ptr() for e in es])
+                arr = lambda i: (ctypes.c_void_p * len(es))(*[e[i] if i == 2 else e[i].data_ptr() for e in es])
                 if _gemm_trace is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -469,6 +476,8 @@ def gemm_nt(x, weight, w_compute, y, M, N, K, ldx, bias=None, aux=None, epi=H.EP
     """y [M, N] = epilogue(x [M, K] W^T + bias), W [N, K]: the forward GEMM of nn.Linear.  `weight` = the float32 master (or a
     view of it; `owner` = its Parameter) when there is one: the fp8 mode then multiplies e4m3 copies (x quantised per row here,
     W per output row, cached); otherwise the bf16 / f32 kernel on `w_compute`."""
+    if _grad_arena is not None and (owner is not None or weight is not None):
+        _grad_arena.note_forward((owner if owner is not None else weight).data_ptr())     # (see deferred_dw.wanted)
     if weight is not None and weight.dtype == torch.float32 and weight.dim() == 2 and _fp8_ok(M, N, K, N, x, y, aux):
         xq, sx = quant_fp8_rows(x, M, K, ldx) if xq is None else xq       # (xq: already quantised by the producing LayerNorm)
         wq, sw = shadows.get_fp8(weight, owner)
