@@ -395,16 +395,19 @@ int fcmf_pack_rgb0(const void* src, int src_dtype, void* dst, int N, int H, int 
                    int pad, int Wp, void* stream);
 /* The 1x1 (plain GEMM: A [M, K] = the NHWC activation, W [N, K]) and implicit-GEMM convolutions with the statistics of the
  * train-mode BatchNorm that follows EVERY convolution of the trunk (torchvision Bottleneck: conv -> bn, resnet_utils.py:13-24) as a
- * by-product of the epilogue: stats [ceil(M / 128)][N][2] float32 <- (sum, sum of squares) of each block of 128 output rows per
- * output channel, of the values as stored (bf16-rounded); plain stores, deterministic.  bf16 only.  FCMF_ERR_UNSUPPORTED where
+ * by-product of the epilogue: stats [ceil(M / R)][N][2] float32 <- (sum, sum of squares) of each block of R output rows per
+ * output channel, of the values as stored (bf16-rounded); plain stores, deterministic.  bf16 only.  R =
+ * fcmf_gemm_colstats_block_rows(ctx, M, N, K): 128 for the 256-column tiles, 256 for the narrow layouts (32 <= N <= 128 with
+ * M >= 8192 and K % 64 == 0), 0 where no kernel emits statistics.  FCMF_ERR_UNSUPPORTED where
  * the shape does not run on the 256-row persistent kernel (M or N < 256, unaligned): run fcmf_gemm / fcmf_conv_gemm +
  * fcmf_bn_stats instead.  fcmf_bn_stats_blocks: those blocks -> the per-group totals inside `sums` (a fcmf_bn_stats_workspace
- * buffer) that fcmf_bn_finalize reads; rows_per_group must be a multiple of 128 (else FCMF_ERR_UNSUPPORTED). */
+ * buffer) that fcmf_bn_finalize reads; rows_per_group must be a multiple of block_rows (else FCMF_ERR_UNSUPPORTED). */
 int fcmf_gemm_colstats(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, float* stats, int M, int N, int K, int64_t lda,
                        int64_t ldb, int64_t ldc, void* stream);
 int fcmf_conv_gemm_colstats(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, float* stats, int n, int Hp, int Wp, int C,
                             int Ho, int Wo, int kh, int kw, int stride, int Cout, void* stream);
-int fcmf_bn_stats_blocks(const float* blockstats, double* sums, int64_t rows_per_group, int groups, int C, void* stream);
+int fcmf_gemm_colstats_block_rows(const fcmf_gemm_ctx* ctx, int M, int N, int K);
+int fcmf_bn_stats_blocks(const float* blockstats, double* sums, int64_t rows_per_group, int groups, int C, int block_rows, void* stream);
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC: [N,H,W,C] -> [N,(H-1)/2+1,(W-1)/2+1,C] */
 int fcmf_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 /* F.adaptive_avg_pool2d(x, [oh, ow]) of an NHWC activation, float32 output: layout 0 = [N, C, oh, ow] (what

@@ -700,12 +700,14 @@ extern "C" int fcmf_bn_stats(const void* x, double* sums, int64_t rows_per_group
 }
 
 // block statistics of a colstats GEMM -> the per-group totals, where fcmf_bn_finalize expects them inside `sums` (a workspace of
-// fcmf_bn_stats_workspace(rows_per_group, groups, C) doubles, as for fcmf_bn_stats).  Groups are whole multiples of 128 rows.
-extern "C" int fcmf_bn_stats_blocks(const float* blockstats, double* sums, int64_t rows_per_group, int groups, int C, void* stream) {
-  if (!blockstats || !sums || rows_per_group <= 0 || groups <= 0 || !bn_shape_ok(C)) return FCMF_ERR_ARG;
-  if (rows_per_group % 128 != 0 || groups > 65535) return FCMF_ERR_UNSUPPORTED;
+// fcmf_bn_stats_workspace(rows_per_group, groups, C) doubles, as for fcmf_bn_stats).  Groups are whole multiples of block_rows
+// (fcmf_gemm_colstats_block_rows of the producing GEMM).
+extern "C" int fcmf_bn_stats_blocks(const float* blockstats, double* sums, int64_t rows_per_group, int groups, int C, int block_rows,
+                                    void* stream) {
+  if (!blockstats || !sums || rows_per_group <= 0 || groups <= 0 || block_rows <= 0 || !bn_shape_ok(C)) return FCMF_ERR_ARG;
+  if (rows_per_group % block_rows != 0 || groups > 65535) return FCMF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(bn_reduce_blocks_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
-                     blockstats, bn_totals(sums, rows_per_group, groups, C), C, (int)(rows_per_group / 128));
+                     blockstats, bn_totals(sums, rows_per_group, groups, C), C, (int)(rows_per_group / block_rows));
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }

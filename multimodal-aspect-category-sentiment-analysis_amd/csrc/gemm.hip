@@ -474,16 +474,25 @@ __device__ __forceinline__ void wait_vm(u32x4 (&r)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
 }
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-template <bool A_TR, bool B_TR, typename TC, int EPI, int MI, int KB, bool FP8 = false, bool BATCH = false>
+// WNW = wave columns (64 output columns each): 4 -> the 256-column tiles above; 2 / 1 -> NARROW outputs (N <= 128 / 64: the
+// 64- and 128-channel convolutions of the ResNet trunk): the same 256-row tile, ring and DMA, but the eight waves stand 4 x 2 or
+// 8 x 1 over 256 x 128 / 256 x 64 outputs (MI = 4 / 2 fragments of 16 rows per wave), so no matrix instruction multiplies the
+// zero-filled columns a 256-column tile would carry (those layers ran on the 128 x 128 kernel at ~370 TFLOP/s, half of it on
+// zeros for N = 64).  K-contiguous operands, 64-deep k-tiles, bf16 output, no epilogue operand.
+template <bool A_TR, bool B_TR, typename TC, int EPI, int MI, int KB, bool FP8 = false, bool BATCH = false, int WNW = 4>
 __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, const BatchPtrs* bp = nullptr) {
   static_assert(!BATCH || (A_TR && B_TR && sizeof(TC) == 4 && MI == 8 && KB == 32), "batched: the weight-gradient kernel");
-  static_assert(MI == 8 || (MI == 6 && !A_TR && sizeof(TC) == 2), "192-row tiles: row-major A, bf16 output");
+  static_assert(WNW == 4 ? (MI == 8 || (MI == 6 && !A_TR && sizeof(TC) == 2))
+                         : ((WNW == 2 && MI == 4) || (WNW == 1 && MI == 2)) && !A_TR && !B_TR && sizeof(TC) == 2 && KB == 64 && !FP8 &&
+                               EPI == FCMF_EPI_NONE,
+                "256-row tiles (192 rows: row-major A, bf16 output); narrow tiles: 4 x 2 / 8 x 1 waves, plain bf16 NT GEMM");
   static_assert(KB == 32 || KB == 64, "k-tile depth");
   static_assert(!FP8 || (KB == 64 && !A_TR && !B_TR && sizeof(TC) == 2), "fp8: K-contiguous operands, bf16 output");
   constexpr int KE = FP8 ? 2 * KB : KB;       // contraction elements per k-tile
   constexpr int NW = 8;
-  constexpr int TM = 32 * MI;                  // block tile rows
   constexpr int WM = 16 * MI;                  // rows per wave
+  constexpr int TM = (8 / WNW) * WM;           // block tile rows (WNW = 4: 32 * MI)
+  constexpr bool FULL_A = TM == 256;           // every wave loads A_PIECES pieces of the A tile
   // dW = dY^T X (both operands transposed, f32 output, no bf16 epilogue slices above the ring): padded transposed image
   constexpr bool PAD_TR = A_TR && B_TR && sizeof(TC) == 4 && KB == 32;
   constexpr int PIECE_STRIDE = PAD_TR ? 1056 : 1024;
@@ -496,11 +505,11 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;     // rows wm*WM, cols wn*64
+  const int wm = wave / WNW, wn = wave % WNW;  // rows wm*WM, cols wn*64 (WNW = 4: wave >> 2, wave & 3)
   // the A tile of the 192-row variant: 12 pieces at KB = 32 (two for waves 0-3, one -- pieces 8..11 -- for waves 4-7),
   // 24 pieces at KB = 64 (three per wave)
-  const int na_pieces = MI == 8 ? A_PIECES : (KB == 64 ? 3 : (wave < 4 ? 2 : 1));
-  const int a_piece0 = MI == 8 ? wave * A_PIECES : (KB == 64 ? wave * 3 : (wave < 4 ? wave * 2 : 4 + wave));
+  const int na_pieces = FULL_A ? A_PIECES : (KB == 64 ? 3 : (wave < 4 ? 2 : 1));
+  const int a_piece0 = FULL_A ? wave * A_PIECES : (KB == 64 ? wave * 3 : (wave < 4 ? wave * 2 : 4 + wave));
 
   // XCD-aware order inside a round: the workgroups of one XCD (blockIdx % 8) take consecutive logical
   // items, and consecutive items share the A row-panel (all N tiles of one M tile) -> L2 hits.
@@ -592,7 +601,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
     if (sa) {
 #pragma unroll
       for (int j = 0; j < A_PIECES; ++j) {
-        if (MI != 8 && j >= na_pieces) break;
+        if (!FULL_A && j >= na_pieces) break;
         char* d = sa + (a_piece0 + j) * PIECE_STRIDE;
         if constexpr (ASM_DMA) {
           if (A_TR) dma16_asm0(wA, lds_addr_of(d), src.a[j] + ka);
@@ -652,7 +661,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
     constexpr int PT = decltype(per_tile)::value;   // DMAs per k-tile of this wave: 4, or 3 for waves 4-7 of the 192-row tile
     const int younger = nkt - 1 - t;
     if constexpr (RING5) {
-      if (a_next > t + 1) { if (MI == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+      if (a_next > t + 1) { if (FULL_A) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       return;
     }
@@ -791,7 +800,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
     }
   } else {
     for (int t = 0; t < nkt; ++t) {
-      wait_landed(t, IntTag<(MI == 8 ? 4 : 3)>{});
+      wait_landed(t, IntTag<(FULL_A ? 4 : 3)>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads of tile t-1 have left LDS
       __builtin_amdgcn_s_barrier();
       if constexpr (FP8) {
@@ -915,7 +924,7 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
             for (int e = 0; e < 8; ++e) {
               const float xv = (float)x[it][e];
               csum[e] += xv;
-              if constexpr (MI == 8 && !HAS_AUX) csq[e] = __builtin_fmaf(xv, xv, csq[e]);   // (colstats; the aux epilogues have no register to spare)
+              if constexpr ((MI == 8 || WNW != 4) && !HAS_AUX) csq[e] = __builtin_fmaf(xv, xv, csq[e]);   // (colstats; the aux epilogues have no register to spare)
             }
           }
         }
@@ -1005,10 +1014,10 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
         if (lane_e < 8 && gj_r < p.N) atomicAdd(p.colsum + gj_r + e, t);
       }
     }
-    if constexpr (MI == 8 && !HAS_AUX) {
-      if (p.colstats && i0 + wm * WM < p.M) {
-        // the wave's 128 rows x 64 columns: lanes that share (lane & 7) share 8 columns; lanes 0-7 store (sum, sum of squares)
-        // of their 8 columns = 64 contiguous bytes of block row (i0 + 128 wm) / 128
+    if constexpr ((MI == 8 || WNW != 4) && !HAS_AUX) {
+      if (p.colstats && (WNW != 4 || i0 + wm * WM < p.M)) {
+        // the wave's WM rows x 64 columns: lanes that share (lane & 7) share 8 columns; lanes 0-7 hold (sum, sum of squares) of
+        // their 8 columns = 64 contiguous bytes of a block row
         float st[16];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1017,10 +1026,36 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
           u += __shfl_xor(u, 8, 64); u += __shfl_xor(u, 16, 64); u += __shfl_xor(u, 32, 64);
           st[2 * e] = t; st[2 * e + 1] = u;
         }
-        if (lane_e < 8 && gj_r < p.N) {
-          float* o = p.colstats + ((int64_t)((i0 + wm * WM) >> 7) * p.N + gj_r) * 2;
+        if constexpr (WNW == 4) {        // 256-column tiles: a wave is a whole 128-row block -- no workgroup traffic
+          if (lane_e < 8 && gj_r < p.N) {
+            float* o = p.colstats + ((int64_t)((i0 + wm * WM) >> 7) * p.N + gj_r) * 2;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(o + 4 * v) = f32x4{st[4 * v], st[4 * v + 1], st[4 * v + 2], st[4 * v + 3]};
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(o + 4 * v) = f32x4{st[4 * v], st[4 * v + 1], st[4 * v + 2], st[4 * v + 3]};
+          }
+        } else {
+          // narrow layouts: the 8 / WNW wave rows of a column group meet in LDS (each wave's own transposition slice, idle now;
+          // the next item's DMA takes that slot only after ITS first barrier) and wave row 0 stores ONE block per 256-row tile
+          // (32- / 64-row blocks made the reduce pass read 4-8x the partial rows from 7 workgroups)
+          float* sl = reinterpret_cast<float*>(slice);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane_e < 8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(sl + lane_e * 16 + 4 * v) = f32x4{st[4 * v], st[4 * v + 1], st[4 * v + 2], st[4 * v + 3]};
+          }
+          lds_barrier();
+          if (wm == 0 && lane_e < 8 && gj_r < p.N) {
+            f32x4 a[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const float* s0 = reinterpret_cast<const float*>(slice - wave * 4096);       // slice of wave 0
+#pragma unroll
+            for (int r = 0; r < 8 / WNW; ++r) {
+              const float* q = s0 + (r * WNW + wn) * 1024 + lane_e * 16;                 // (4096 bytes = 1024 floats per wave)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) a[v] += *reinterpret_cast<const f32x4*>(q + 4 * v);
+            }
+            float* o = p.colstats + ((int64_t)(i0 >> 8) * p.N + gj_r) * 2;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(o + 4 * v) = a[v];
+          }
         }
       }
     }
@@ -1301,6 +1336,13 @@ template <bool A_TR, bool B_TR, typename TC, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_tile256_kernel(GemmParams p) {
   gemm_bf16_tile256_body<A_TR, B_TR, TC, EPI, 8, 32>(p);
 }
+// narrow outputs (see the body): N <= 128 -> 4 x 2 waves of 64 x 64; N <= 64 -> 8 x 1 waves of 32 x 64
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tile256k64_n128_kernel(GemmParams p) {
+  gemm_bf16_tile256_body<false, false, bf16_t, FCMF_EPI_NONE, 4, 64, false, false, 2>(p);
+}
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tile256k64_n64_kernel(GemmParams p) {
+  gemm_bf16_tile256_body<false, false, bf16_t, FCMF_EPI_NONE, 2, 64, false, false, 1>(p);
+}
 // up to BATCH_MAX same-shape weight gradients dW_i (+)= dY_i^T X_i in ONE launch: the tiles of all matrices form one work list
 // (a layer's 768 x 768 gradient alone is 9 tiles: it filled the chip only through a 28-way split of K, whose partial tiles then
 // cost a reduce pass per matrix)
@@ -1483,6 +1525,17 @@ extern "C" const char* fcmf_gemm_ctx_last_kernel(const fcmf_gemm_ctx* ctx) { ret
 
 struct ConvGeom { int C, logC, Hp, Wp, Ho, Wo, kw, stride; int64_t in_bytes; int logP; };
 
+// shapes of the narrow-output layouts of the persistent kernel (N <= 64: 8 x 1 waves of 32 rows; N <= 128: 4 x 2 waves of 64 rows)
+static bool narrow_shape(int M, int N, int K) { return N >= 32 && N <= 128 && N % 8 == 0 && K % 64 == 0 && M >= 8192; }
+
+// rows per block of the statistics fcmf_gemm_colstats / fcmf_conv_gemm_colstats emit for an [M, N] output contracted over K:
+// 128 (256-column tiles), 256 (narrow layouts: one block per tile), 0 where no kernel emits them (the GEMM call then returns FCMF_ERR_UNSUPPORTED)
+extern "C" int fcmf_gemm_colstats_block_rows(const fcmf_gemm_ctx* ctx, int M, int N, int K) {
+  const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
+  if (cfg.force_tile == 0 && cfg.kb64 && narrow_shape(M, N, K)) return 256;
+  return (M >= 256 && N >= 256 && N % 8 == 0) ? 128 : 0;
+}
+
 static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
                      int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
                      int out_dtype, int epilogue, int accumulate, void* stream, const ConvGeom* cv, float* colstats = nullptr) {
@@ -1533,6 +1586,29 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
                  ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (splittable && K >= 512));
     if (cfg.force_tile == 128) large = false;
     if (cfg.force_tile == 256 || cfg.force_tile == 192) large = tile_ok;
+    // narrow outputs with many rows (the trunk's 64- / 128-channel convolutions): the persistent kernel's 4 x 2 / 8 x 1 wave layouts
+    const bool narrow = cfg.force_tile == 0 && cfg.kb64 && tile_ok && !colsum && !aux && !accumulate && !trans_a && !trans_b &&
+                        out_dtype == FCMF_BF16 && epilogue == FCMF_EPI_NONE && narrow_shape(M, N, K);
+    if (narrow) {
+      p.ksplit = 1; p.ktiles_per_split = K / 64;
+      p.tiles = (M + GB - 1) / GB; p.total_items = p.tiles;
+      p.ws = nullptr;
+      p.nt_out = (int64_t)M * N * 2 >= cfg.nt_min_bytes;
+      const dim3 grid(p.total_items < cfg.num_cus ? p.total_items : cfg.num_cus);
+      const size_t smem = (size_t)RING_BYTES + 8 * 4096;
+      snprintf(last_kernel, NAME, "gemm_bf16_tile256k64_n%d_kernel", N <= 64 ? 64 : 128);
+      if (N <= 64) {
+        auto k = gemm_bf16_tile256k64_n64_kernel;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+      } else {
+        auto k = gemm_bf16_tile256k64_n128_kernel;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(512), smem, st, p);
+      }
+      FCMF_CHECK_LAUNCH();
+      return FCMF_OK;
+    }
     if (colstats) {       // block statistics exist in the 256-row bf16 kernels only: the caller falls back to a statistics pass
       // (they were built into the 128 x 128 kernel too -- the trunk's 64 / 128-channel layers -- and measured: its epilogue, a
       //  fragment-layout one, pays as much for the rounding, the 128 shuffles and two barriers as the separate pass costs)

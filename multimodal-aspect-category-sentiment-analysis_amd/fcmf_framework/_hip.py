@@ -94,7 +94,8 @@ SIGNATURES = {
     "fcmf_pack_rgb0": [_vp, _i, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
     "fcmf_gemm_colstats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp],
     "fcmf_conv_gemm_colstats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "fcmf_bn_stats_blocks": [_vp, _vp, _i64, _i, _i, _vp],
+    "fcmf_gemm_colstats_block_rows": [_vp, _i, _i, _i],
+    "fcmf_bn_stats_blocks": [_vp, _vp, _i64, _i, _i, _i, _vp],
     "fcmf_bn_finalize_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _f, _f, _i, _i, _i, _i, _i, _vp],
     "fcmf_maxpool3x3s2": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "fcmf_adaptive_avgpool": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

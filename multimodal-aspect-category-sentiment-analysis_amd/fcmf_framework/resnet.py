@@ -85,12 +85,15 @@ FUSED_BN_APPLY = True     # tests flip this to compare fcmf_bn_finalize_apply wi
 FUSED_BN_STATS = True     # tests flip this to compare the GEMM-epilogue block statistics with the separate statistics pass
 
 
-def _block_stats(rows, Cout, dtype, device):
-    """buffer for the (sum, sum of squares) per block of 128 output rows and channel that a colstats GEMM emits, or None where
-    that kernel does not apply (the caller then runs the statistics pass)"""
-    if not FUSED_BN_STATS or dtype != torch.bfloat16 or rows < 256 or Cout < 256 or Cout % 8:
+def _block_stats(rows, Cout, K, dtype, device):
+    """(buffer, rows per block) for the (sum, sum of squares) per block of output rows and channel that a colstats GEMM emits, or
+    None where no kernel emits them (the caller then runs the statistics pass)"""
+    if not FUSED_BN_STATS or dtype != torch.bfloat16:
         return None
-    return torch.empty(((rows + 127) // 128, Cout, 2), dtype=torch.float32, device=device)
+    br = H.lib().fcmf_gemm_colstats_block_rows(H.gemm_ctx(), rows, Cout, K)
+    if br <= 0:
+        return None
+    return torch.empty(((rows + br - 1) // br, Cout, 2), dtype=torch.float32, device=device), br
 
 
 def conv2d_implicit(xp, conv, N, Ho, Wo, stats=False):
@@ -102,9 +105,9 @@ def conv2d_implicit(xp, conv, N, Ho, Wo, stats=False):
     wm, Kpad = _weight_matrix(conv, xp.dtype)
     assert Kpad == kh * kw * C
     y = torch.empty((N * Ho * Wo, Cout), dtype=xp.dtype, device=xp.device)
-    blocks = _block_stats(N * Ho * Wo, Cout, xp.dtype, xp.device) if stats else None
+    blocks = _block_stats(N * Ho * Wo, Cout, Kpad, xp.dtype, xp.device) if stats else None
     if blocks is not None:
-        rc = H.lib().fcmf_conv_gemm_colstats(H.gemm_ctx(), H.ptr(xp), H.ptr(wm), H.ptr(y), H.ptr(blocks), N, xp.shape[1], xp.shape[2],
+        rc = H.lib().fcmf_conv_gemm_colstats(H.gemm_ctx(), H.ptr(xp), H.ptr(wm), H.ptr(y), H.ptr(blocks[0]), N, xp.shape[1], xp.shape[2],
                                              C, Ho, Wo, kh, kw, conv.stride[0], Cout, H.stream())
         if rc == H.ERR_UNSUPPORTED:
             blocks = None
@@ -146,8 +149,8 @@ def conv2d_stem(v, conv, stats=False):
         return ops.cast(w.view(Cout, k * 32).contiguous(), torch.bfloat16)
     wm = ops.shadows.derived(conv.weight, ("stem_runs", torch.bfloat16), build)
     y = torch.empty((N * Ho * Wo, Cout), dtype=torch.bfloat16, device=v.device)
-    blocks = _block_stats(N * Ho * Wo, Cout, torch.bfloat16, v.device) if stats else None
-    H.check(H.lib().fcmf_conv_gemm_runs(H.gemm_ctx(), H.ptr(buf), H.ptr(wm), H.ptr(y), H.ptr(blocks), N, Hh + 2 * pad, Wp, 4, 32, Ho, Wo, k, 2,
+    blocks = _block_stats(N * Ho * Wo, Cout, k * 32, torch.bfloat16, v.device) if stats else None
+    H.check(H.lib().fcmf_conv_gemm_runs(H.gemm_ctx(), H.ptr(buf), H.ptr(wm), H.ptr(y), H.ptr(blocks[0]) if blocks is not None else None, N, Hh + 2 * pad, Wp, 4, 32, Ho, Wo, k, 2,
                                         Cout, H.stream()), "fcmf_conv_gemm_runs")
     y = y.view(N, Ho, Wo, Cout)
     return (y, blocks) if stats else y
@@ -177,9 +180,9 @@ def conv2d_nhwc(x, conv, src_strides=None, stats=False):
         H.check(H.lib().fcmf_conv_im2col(H.ptr(x), H.dt(x), H.ptr(A), H.dt(A), N, Hh, Ww, C, sn, sh, sw, sc, kh, kw, st,
                                          pad, Kpad, H.stream()), "fcmf_conv_im2col")
     y = torch.empty((rows, Cout), dtype=dt, device=x.device)
-    blocks = _block_stats(rows, Cout, dt, x.device) if stats else None
+    blocks = _block_stats(rows, Cout, Kpad, dt, x.device) if stats else None
     if blocks is not None:
-        rc = H.lib().fcmf_gemm_colstats(H.gemm_ctx(), H.ptr(A), H.ptr(wm), H.ptr(y), H.ptr(blocks), rows, Cout, Kpad, Kpad, Kpad, Cout,
+        rc = H.lib().fcmf_gemm_colstats(H.gemm_ctx(), H.ptr(A), H.ptr(wm), H.ptr(y), H.ptr(blocks[0]), rows, Cout, Kpad, Kpad, Kpad, Cout,
                                         H.stream())
         if rc == H.ERR_UNSUPPORTED:
             blocks = None
@@ -194,8 +197,8 @@ def conv2d_nhwc(x, conv, src_strides=None, stats=False):
 def batchnorm_nhwc_(y, bn, groups=1, res=None, relu=False, out=None, save=None, out_pad=0, blocks=None):
     """BatchNorm2d (+ residual, + ReLU) of y [N,H,W,C], in place (or into `out`); training mode: per-group batch
     statistics and `groups` running-statistics updates (module docstring).  save: dict that receives mean / rstd /
-    groups / training for the backward.  blocks: the block statistics the producing convolution emitted (conv2d_nhwc(...,
-    stats=True)): the statistics pass over y is skipped when every group is a whole number of 128-row blocks."""
+    groups / training for the backward.  blocks: (block statistics, rows per block) the producing convolution emitted
+    (conv2d_nhwc(..., stats=True)): the statistics pass over y is skipped when every group is a whole number of blocks."""
     N, Hh, Ww, C = y.shape
     rows = N * Hh * Ww
     L, st = H.lib(), H.stream()
@@ -207,8 +210,8 @@ def batchnorm_nhwc_(y, bn, groups=1, res=None, relu=False, out=None, save=None, 
             raise H.HipLibraryError(f"grouped BatchNorm: {N} crops do not split into {groups} equal groups")
         rpg = rows // groups
         sums = torch.empty(L.fcmf_bn_stats_workspace(rpg, groups, C), dtype=torch.float64, device=dev)
-        if blocks is not None and rpg % 128 == 0:
-            H.check(L.fcmf_bn_stats_blocks(H.ptr(blocks), H.ptr(sums), rpg, groups, C, st), "fcmf_bn_stats_blocks")
+        if blocks is not None and rpg % blocks[1] == 0:
+            H.check(L.fcmf_bn_stats_blocks(H.ptr(blocks[0]), H.ptr(sums), rpg, groups, C, blocks[1], st), "fcmf_bn_stats_blocks")
         else:
             H.check(L.fcmf_bn_stats(H.ptr(y), H.ptr(sums), rpg, groups, C, H.dt(y), st), "fcmf_bn_stats")
         mom = 0.1 if bn.momentum is None else float(bn.momentum)

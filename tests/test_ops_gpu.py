@@ -1125,3 +1125,22 @@ def test_gemm_dw_batched_matches_separate_weight_gradients(dev, count, N, K, Mto
         assert rel_err(got[i], ref) < 2e-3 and rel_err(got[i], want[i]) < 1e-5, i
     two = (ctypes.c_void_p * 2)(dYs[0].data_ptr(), dYs[0].data_ptr())
     assert H.lib().fcmf_gemm_dw_batched(ctx, 2, two, None, None, N, K, Mtok, N, K, K, acc, H.stream()) == -1        # missing pointer tables
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(8192, 64, 256, False), (9000, 64, 576, True), (8200, 128, 1152, False), (16384, 96, 128, True),
+                                        (8192, 32, 64, False), (8192, 128, 64, False)])
+def test_gemm_narrow_outputs_on_the_persistent_kernel(dev, M, N, K, bias):
+    """N <= 128 with many rows (the ResNet trunk's 64- / 128-channel convolutions as GEMMs): the 256-row persistent kernel with its
+    eight waves standing 8 x 1 (N <= 64) or 4 x 2 (N <= 128) over the outputs -- no matrix instruction on zero-filled columns.
+    Against the float64 product of the same bf16 operands; ragged row counts, N that is no multiple of 64, a bias, K of one k-tile."""
+    ops, H = _ops()
+    x, w = _rand((M, K), dev, torch.bfloat16, seed=1), _rand((N, K), dev, torch.bfloat16, seed=2)
+    b = _rand((N,), dev, seed=3) if bias else None
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.gemm(x, w, y, M, N, K, K, K, N, 0, 0, bias=b)
+    assert H.last_gemm_kernel() == ("gemm_bf16_tile256k64_n64_kernel" if N <= 64 else "gemm_bf16_tile256k64_n128_kernel")
+    ref = x.double().cpu() @ w.double().cpu().t()
+    if bias:
+        ref = ref + b.double().cpu()
+    assert torch.isfinite(y).all()
+    assert rel_err(y, ref) < 6e-3

@@ -249,12 +249,14 @@ def test_cpu_tensors_are_loud(dev):
 
 
 @pytest.mark.parametrize("C,Cout,k,stride,N,hw", [(64, 64, 3, 1, 5, 14), (128, 128, 3, 2, 3, 28), (256, 256, 3, 1, 70, 14), (512, 512, 3, 2, 9, 14),
-                                                  (256, 512, 1, 2, 4, 56), (1024, 2048, 1, 2, 3, 14), (64, 64, 3, 1, 2, 56)])
+                                                  (256, 512, 1, 2, 4, 56), (1024, 2048, 1, 2, 3, 14), (64, 64, 3, 1, 2, 56),
+                                                  (64, 64, 3, 1, 3, 56), (128, 128, 3, 2, 12, 56)])
 def test_implicit_gemm_convolution_matches_patch_matrix_and_torch(dev, C, Cout, k, stride, N, hw):
     """fcmf_conv_gemm (no patch matrix: the GEMM's LDS-DMA walks the taps of every receptive field in the zero-bordered NHWC
     activation) against (1) the explicit fcmf_conv_im2col + fcmf_gemm path on the same bf16 data -- same products, f32
-    accumulation in a different k order at most -- and (2) F.conv2d in float32; both the 128x128 kernel (Cout < 256) and
-    the persistent 256 / 192-row kernels (Cout >= 256, M x N large), stride 1 and 2, ragged row counts, 3x3 (padded input
+    accumulation in a different k order at most -- and (2) F.conv2d in float32; the 128x128 kernel (Cout < 256, few rows), the
+    narrow-output layouts of the persistent kernel (Cout <= 128 with >= 8192 output pixels: the last two cases) and the
+    persistent 256 / 192-row kernels (Cout >= 256, M x N large), stride 1 and 2, ragged row counts, 3x3 (padded input
     written by fcmf_bn_apply_pad) and the strided 1x1 shortcut (unpadded input)."""
     from fcmf_framework import _hip as H, ops, resnet as R
     _set(torch.bfloat16)
@@ -290,11 +292,12 @@ def test_implicit_gemm_convolution_matches_patch_matrix_and_torch(dev, C, Cout, 
 
 
 @pytest.mark.parametrize("C,Cout,k,stride,N,hw,groups", [(64, 256, 1, 1, 8, 16, 2), (256, 256, 3, 1, 6, 16, 3), (512, 1024, 1, 2, 8, 16, 4),
-                                                         (128, 512, 1, 1, 3, 20, 1), (256, 1024, 1, 1, 7, 14, 7)])
+                                                         (128, 512, 1, 1, 3, 20, 1), (256, 1024, 1, 1, 7, 14, 7),
+                                                         (64, 64, 3, 1, 3, 56, 3), (256, 128, 1, 1, 12, 28, 3), (64, 256, 1, 1, 3, 56, 1)])
 def test_convolution_emits_the_batchnorm_statistics_of_its_output(dev, C, Cout, k, stride, N, hw, groups):
     """fcmf_gemm_colstats / fcmf_conv_gemm_colstats + fcmf_bn_stats_blocks against the convolution followed by the separate
     statistics pass (fcmf_bn_stats): the output tensor is bit-identical; the block statistics are the exact f32 sums of the
-    STORED bf16 values over 128 rows (checked against a float64 sum of the output); the BatchNorm that consumes them gives the
+    STORED bf16 values over fcmf_gemm_colstats_block_rows rows (128; 256 for the narrow layouts: the last cases) (checked against a float64 sum of the output); the BatchNorm that consumes them gives the
     same result as the two-pass path to bf16 rounding, running statistics included.  Cases: 1x1 plain GEMM, 3x3 implicit, strided
     1x1 implicit, a row count that is no multiple of 128 (ragged last block; the group then falls back to the pass), 7 groups."""
     from fcmf_framework import _hip as H, ops, resnet as R
@@ -329,13 +332,15 @@ def test_convolution_emits_the_batchnorm_statistics_of_its_output(dev, C, Cout, 
         y0, b0, z0, rm0, rv0, _ = run(False)
         y1, b1, z1, rm1, rv1, kern = run(True)
         assert b0 is None and b1 is not None and "tile256" in kern, kern
+        b1, br = b1                                              # (block statistics, rows per block: 128; narrow layouts: 256)
+        assert br == (128 if Cout >= 256 else 256)
         assert torch.equal(y0, y1)
         yf = y1.view(rows, Cout).double().cpu()
-        nb = (rows + 127) // 128
+        nb = (rows + br - 1) // br
         assert b1.shape == (nb, Cout, 2)
-        padded = torch.zeros(nb * 128, Cout, dtype=torch.float64)
+        padded = torch.zeros(nb * br, Cout, dtype=torch.float64)
         padded[:rows] = yf
-        want_s, want_q = padded.view(nb, 128, Cout).sum(1), (padded ** 2).view(nb, 128, Cout).sum(1)
+        want_s, want_q = padded.view(nb, br, Cout).sum(1), (padded ** 2).view(nb, br, Cout).sum(1)
         assert max_err(b1[..., 0].cpu().double(), want_s) < 1e-5 * want_s.abs().max().item()
         assert max_err(b1[..., 1].cpu().double(), want_q) < 1e-5 * want_q.abs().max().item()
         assert max_err(z1, z0) <= 2 ** -7 * z0.float().abs().max().item()
