@@ -94,7 +94,7 @@ class _SelfQuirkAttentionFn(torch.autograd.Function):
         G, T, E = x.shape
         x2 = ops._rows(x)
         HD = wk.shape[0] * wk.shape[2]
-        wl, _ = _pair_layouts(wk, wq, x2.dtype)
+        wl = ops.shadows.head_nk([wk, wq]) if x2.dtype == torch.bfloat16 else _pair_layouts(wk, wq, x2.dtype)[0]
         kq = torch.empty((G * T, 2 * HD), dtype=x2.dtype, device=x2.device)
         ops.gemm(x2, wl, kq, G * T, 2 * HD, E, ops._ld(x2), E, 2 * HD, 0, 0)
         kq3 = kq.view(G, T, 2 * HD)
@@ -114,9 +114,12 @@ class _SelfQuirkAttentionFn(torch.autograd.Function):
         dkq = torch.empty_like(kq)
         d3 = dkq.view(G, T, 2 * HD)
         _quirk_attn_bwd(kq3[:, :, HD:], kq3[:, :, :HD], out, lse, dout, heads, causal, d3[:, :, HD:], d3[:, :, :HD])
-        _, kn = _pair_layouts(wk, wq, x2.dtype)
         dx = torch.empty((G * T, E), dtype=x2.dtype, device=x2.device)
-        ops.gemm(dkq, kn(), dx, G * T, E, 2 * HD, 2 * HD, 2 * HD, E, 0, 0)                   # NT: both operands K-contiguous
+        if x2.dtype == torch.bfloat16:     # NN: dx = dkq W with W in the forward's [2*n_head*d, E] layout (no second re-layout)
+            ops.gemm(dkq, ops.shadows.head_nk([wk, wq]), dx, G * T, E, 2 * HD, 2 * HD, E, E, 0, 1)
+        else:
+            _, kn = _pair_layouts(wk, wq, x2.dtype)
+            ops.gemm(dkq, kn(), dx, G * T, E, 2 * HD, 2 * HD, 2 * HD, E, 0, 0)               # NT: both operands K-contiguous
         dwl = torch.empty((2 * HD, E), dtype=torch.float32, device=x2.device)
         ops.gemm(dkq, x2, dwl, 2 * HD, E, G * T, 2 * HD, ops._ld(x2), E, 1, 1)                # [2*n_head*d, E] = dkq^T x
         dw = dwl.view(2, nh, d, E).permute(0, 1, 3, 2)                                        # -> the parameters' [n_head, E, d]
@@ -137,7 +140,8 @@ class _HoistedKeysFn(torch.autograd.Function):
 
         def nk(_):
             return ops.cast(torch.cat([w.detach().permute(0, 2, 1).reshape(HD, E) for w in wks], 0), e2.dtype)
-        wl = ops.shadows.derived(wks[0], ("hoist_nk", e2.dtype, nb, wks[-1].data_ptr()), nk)
+        wl = (ops.shadows.head_nk(list(wks)) if e2.dtype == torch.bfloat16
+              else ops.shadows.derived(wks[0], ("hoist_nk", e2.dtype, nb, wks[-1].data_ptr()), nk))
         kx = torch.empty((G * T, nb * HD), dtype=e2.dtype, device=e2.device)
         ops.gemm(e2, wl, kx, G * T, nb * HD, E, ops._ld(e2), E, nb * HD, 0, 0)
         ctx.save_for_backward(e2, *wks)
@@ -162,9 +166,12 @@ class _HoistedKeysFn(torch.autograd.Function):
 
         def kn(_):
             return ops.cast(torch.cat([w.detach().permute(1, 0, 2).reshape(E, HD) for w in wks], 1), e2.dtype)
-        wt = ops.shadows.derived(wks[0], ("hoist_kn", e2.dtype, nb, wks[-1].data_ptr()), kn)
         de = torch.empty((G * T, E), dtype=e2.dtype, device=e2.device)
-        ops.gemm(dk, wt, de, G * T, E, nb * HD, nb * HD, nb * HD, E, 0, 0)
+        if e2.dtype == torch.bfloat16:
+            ops.gemm(dk, ops.shadows.head_nk(list(wks)), de, G * T, E, nb * HD, nb * HD, E, E, 0, 1)       # NN
+        else:
+            wt = ops.shadows.derived(wks[0], ("hoist_kn", e2.dtype, nb, wks[-1].data_ptr()), kn)
+            ops.gemm(dk, wt, de, G * T, E, nb * HD, nb * HD, nb * HD, E, 0, 0)
         dwl = torch.empty((nb * HD, E), dtype=torch.float32, device=e2.device)
         ops.gemm(dk, e2, dwl, nb * HD, E, G * T, nb * HD, ops._ld(e2), E, 1, 1)
         dw = dwl.view(nb, nh, d, E).permute(0, 1, 3, 2)

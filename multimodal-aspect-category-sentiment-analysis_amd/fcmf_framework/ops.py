@@ -79,6 +79,7 @@ class _Shadows:
         self.mapD = {}
         self.mapQ = {}
         self.mapQT = {}
+        self.mapH = {}
         self._mt_tables = None
 
     def get_t(self, w, owner=None):
@@ -140,6 +141,40 @@ class _Shadows:
         for _, ent in items:
             ent[2] = False
             ent[1] = ent[4]()._version       # fresh as of the owner's current version
+
+    def head_nk(self, ws):
+        """bf16 [len(ws) * n_head * d, E] re-layout ("nn.Linear layout", natural head order) of the per-head weights `ws` (float32
+        Parameters [n_head, E, d] of the IAOG decoder's Attention): row (i * n_head + h) * d + j = ws[i][h, :, j].  Every [d, E]
+        row block is the transpose of the dense [E, d] slice ws[i][h] and is REGISTERED as one of the transposed copies, so
+        `refresh_transposed` rebuilds all of them -- every block of the decoder -- in the optimizer's one launch (the round-2 form
+        rebuilt each layout with permute + reshape copies, a cat and a cast per step and block: 130 launches).  With another
+        optimizer the first use after an update refreshes everything, also in one launch."""
+        key = tuple(w.data_ptr() for w in ws) + (tuple(ws[0].shape),)
+        ent = self.mapH.get(key)
+        if ent is None or any(r() is None for r in ent[2]):
+            nh, E, d = ws[0].shape
+            buf = torch.empty((len(ws) * nh * d, E), dtype=torch.bfloat16, device=ws[0].device)
+            pieces = []
+            for i, w in enumerate(ws):
+                if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (nh, E, d):
+                    raise H.HipLibraryError("head_nk: dense float32 [n_head, E, d] parameters expected")
+                for h in range(nh):
+                    src, dst = w.detach()[h], buf[(i * nh + h) * d:(i * nh + h + 1) * d]
+                    k2 = (src.data_ptr(), (E, d))
+                    self.mapT[k2] = [dst, -1, True, True, weakref.ref(w), src.data_ptr() - w.data_ptr()]
+                    pieces.append(k2)
+            self._mt_tables = None
+            ent = self.mapH[key] = (buf, pieces, [weakref.ref(w) for w in ws])
+        buf, pieces, owners = ent
+        for k2 in pieces:
+            e = self.mapT.get(k2)
+            if e is None or e[2] or e[1] != e[4]()._version:
+                if e is None:              # (pruned: the parameter moved) -- start over
+                    del self.mapH[key]
+                    return self.head_nk(ws)
+                self.refresh_transposed()
+                break
+        return buf
 
     def get_fp8(self, w, owner=None):
         """(q [N, K] e4m3 bytes, scale [N] float32) of a float32 [N, K] weight, quantised per output row; rebuilt lazily
@@ -237,6 +272,7 @@ class _Shadows:
         self.mapD.clear()
         self.mapQ.clear()
         self.mapQT.clear()
+        self.mapH.clear()
         self._mt_tables = None
 
 
@@ -608,7 +644,7 @@ class HeadLinearFn(torch.autograd.Function):
     def forward(ctx, x, w):
         x2 = _rows(x)
         nh, E, d = w.shape
-        wl, _ = HeadLinearFn._layouts(w, x2.dtype)
+        wl = shadows.head_nk([w]) if x2.dtype == torch.bfloat16 else HeadLinearFn._layouts(w, x2.dtype)[0]
         y = _linear_fwd(x2, wl, None)
         ctx.save_for_backward(x2, w)
         ctx.xshape = x.shape
@@ -622,9 +658,12 @@ class HeadLinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, N).contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            _, kn = HeadLinearFn._layouts(w, x2.dtype)
             dx = torch.empty((M, E), dtype=dy2.dtype, device=dy2.device)
-            gemm(dy2, kn(), dx, M, E, N, N, N, E, 0, 0)                      # NT: both operands K-contiguous
+            if dy2.dtype == torch.bfloat16:
+                gemm(dy2, shadows.head_nk([w]), dx, M, E, N, N, E, E, 0, 1)      # NN: dx = dy W with W in the forward's [N, E] layout
+            else:
+                _, kn = HeadLinearFn._layouts(w, x2.dtype)
+                gemm(dy2, kn(), dx, M, E, N, N, N, E, 0, 0)                  # NT: both operands K-contiguous
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dwl = torch.empty((N, E), dtype=torch.float32, device=dy2.device)    # (fresh buffer: written, not accumulated into)
