@@ -283,3 +283,26 @@ def test_default_bucket_plan_for_fcmf_base_geometry():
     assert all(k < 12e6 for _, k in buckets[:-1])                      # <= 48 MB each
     assert "word_embeddings" in buckets[-1][0] and buckets[-1][1] >= 49e6
     assert dp.GradReducer.__init__.__defaults__[0] == 32
+
+
+def test_grad_arena_counts_forward_uses_for_the_deferred_weight_gradients():
+    """GradArena.fwd_uses / used_once (the gate of ops.deferred_dw): a weight-gradient GEMM may be delayed to the end of the backward
+    pass only if its destination slice belongs to a parameter that exactly ONE forward GEMM used since zero() -- a weight that is
+    applied twice has two gradient producers, and autograd adds their results the moment each Function returns.  CPU, no kernels."""
+    sys.path.insert(0, PKG)
+    from fcmf_framework.dp import GradArena
+    a, b, c = (torch.nn.Parameter(torch.randn(8, 8)) for _ in range(3))
+    arena = GradArena([a, b, c])
+    try:
+        slice_of = lambda p: arena.view[id(p)].data_ptr()
+        assert not arena.used_once(slice_of(a))                       # never used: not eligible (unknown producers)
+        arena.note_forward(a.data_ptr())
+        arena.note_forward(b.data_ptr()); arena.note_forward(b.data_ptr())
+        assert arena.used_once(slice_of(a)) and not arena.used_once(slice_of(b)) and not arena.used_once(slice_of(c))
+        assert not arena.used_once(slice_of(a) + 4)                   # an address inside a slice is no slice start
+        arena.zero()                                                  # a new step: counts start over
+        assert not arena.used_once(slice_of(a))
+        arena.note_forward(b.data_ptr())
+        assert arena.used_once(slice_of(b))
+    finally:
+        arena.deactivate()
