@@ -571,7 +571,7 @@ def _linear_fwd(x, w, bias, epi=H.EPI_NONE, aux=None, master=None):
     return y
 
 
-def _linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=True, dx_epi=H.EPI_NONE, dx_aux=None, master=None):
+def _linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=True, dx_epi=H.EPI_NONE, dx_aux=None, master=None, bias_param=None):
     """x [M,K], w [N,K] (compute dtype), dy [M,N] -> dx [M,K], dW [N,K] f32, db [N] f32
     (master = the float32 parameter behind w, if any: bf16 mode then uses its transposed copy for dx)"""
     M, K = x.shape
@@ -586,7 +586,12 @@ def _linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=True, dx_epi=H.EPI
             torch.zeros((N, K), dtype=torch.float32, device=dy.device)
         gemm(dy, x, dw, N, K, M, N, _ld(x), K, 1, 1, acc=True)
     if need_db:
-        db = colsum(dy, M, N, N)
+        if bias_param is not None and bias_param.dtype == torch.float32 and tuple(bias_param.shape) == (N,):
+            # straight into the parameter's (already zero) arena slice: no output tensor, no memset inside fcmf_colsum
+            db = alloc_grad(bias_param, (N,))
+            H.check(H.lib().fcmf_colsum(H.ptr(dy), H.ptr(db), M, N, N, H.dt(dy), 1, H.stream()), "fcmf_colsum")
+        else:
+            db = colsum(dy, M, N, N)
     return dx, dw, db
 
 
@@ -602,6 +607,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, weight, y if act == "tanh" else None)
         ctx.act = act
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], weight.shape[0])
 
@@ -615,7 +621,7 @@ class LinearFn(torch.autograd.Function):
             dy2 = d
         w = as_compute(weight, x2.dtype)
         dx, dw, db = _linear_bwd(x2, w, dy2, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                 ctx.has_bias and ctx.needs_input_grad[2], master=weight)
+                                 ctx.has_bias and ctx.needs_input_grad[2], master=weight, bias_param=ctx.bias_param)
         return (None if dx is None else dx.view(ctx.xshape)), dw, db, None
 
 
