@@ -15,14 +15,16 @@ from review_batches import ASPECTS, ReviewProducer
 
 class IAOGDataset(torch.utils.data.Dataset):
     def __init__(self, data, tokenizer, img_folder, roi_df, dict_image_aspect, dict_roi_aspect, num_img=7, num_roi=4,
-                 max_len_decoder=20, image_loader=None, feature_cache=None):
+                 max_len_decoder=20, image_loader=None, feature_cache=None, max_seq_length=None, list_aspect=None):
+        """max_seq_length / list_aspect: the driver's --max_seq_length / --list_aspect (the reference accepts both flags and
+        hard-codes 170 positions and the six categories in its dataset: those are the defaults here)"""
         self.data, self.tokenizer = data, tokenizer
         self.num_img, self.num_roi, self.max_len_decoder = num_img, num_roi, max_len_decoder
-        self.ASPECT = list(ASPECTS)
+        self.ASPECT = list(list_aspect) if list_aspect else list(ASPECTS)
         self.aspect2id = {a: i for i, a in enumerate(self.ASPECT)}
         self.producer = ReviewProducer(tokenizer, img_folder, roi_df, dict_image_aspect, dict_roi_aspect, num_img, num_roi,
                                        image_loader=image_loader, feature_cache=feature_cache, roi_dtype=torch.float32,
-                                       clamp_boxes=True)
+                                       clamp_boxes=True, seq_len=max_seq_length)
         self.samples = []
         for idx, row in self.data.iterrows():
             words_of = {}

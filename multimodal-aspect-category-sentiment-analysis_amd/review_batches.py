@@ -51,13 +51,14 @@ def display_name(aspect):
 
 class ReviewProducer:
     def __init__(self, tokenizer, img_folder, roi_df, dict_image_aspect, dict_roi_aspect, num_img, num_roi,
-                 image_loader=None, feature_cache=None, roi_dtype=torch.float64, clamp_boxes=False, crop_size=224):
+                 image_loader=None, feature_cache=None, roi_dtype=torch.float64, clamp_boxes=False, crop_size=224, seq_len=None):
         self.tokenizer, self.img_folder, self.roi_df = tokenizer, img_folder, roi_df
         self.tags_img, self.tags_roi = dict_image_aspect, dict_roi_aspect
         self.num_img, self.num_roi = num_img, num_roi
         self.load = image_loader or default_image_loader
         self.cache = feature_cache
         self.roi_dtype, self.clamp_boxes, self.size = roi_dtype, clamp_boxes, crop_size
+        self.seq_len = int(seq_len) if seq_len else SEQ_LEN
 
     # ---- text side -------------------------------------------------------------------------------------------
     def visual_tags(self, photos):
@@ -71,10 +72,10 @@ class ReviewProducer:
         """-> (input_ids, token_type_ids, attention_mask, added_mask) of the two-segment prompt"""
         first = f"{display_name(aspect)} </s></s> {text}".lower().replace('_', ' ')
         second = f" {' , '.join(tags[0])} </s></s>  {' , '.join(tags[1])}".lower().replace('_', ' ')
-        tok = self.tokenizer(first, second, max_length=SEQ_LEN, truncation='only_first', padding='max_length',
+        tok = self.tokenizer(first, second, max_length=self.seq_len, truncation='only_first', padding='max_length',
                              return_token_type_ids=True)
         as_t = lambda k: torch.as_tensor(tok[k]).reshape(-1)
-        return as_t('input_ids'), as_t('token_type_ids'), as_t('attention_mask'), torch.ones(SEQ_LEN + PATCHES, dtype=torch.long)
+        return as_t('input_ids'), as_t('token_type_ids'), as_t('attention_mask'), torch.ones(self.seq_len + PATCHES, dtype=torch.long)
 
     # ---- image side ------------------------------------------------------------------------------------------
     def _boxes_of(self, name):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """IAOG seq2seq pre-training driver on MI355X -- drop-in for the reference's run_pretraining_fcmf.py.
 
-Same flags (reference run_pretraining_fcmf.py:45-84), same step (:284-337: FCMFSeq2Seq forward,
+Accepts every flag the reference declares (run_pretraining_fcmf.py:45-84; tests/test_surface.py feeds it the published
+command line of Pretraining-Notebook.ipynb:6927-6945), same step (:284-337: FCMFSeq2Seq forward,
 CE(ignore_index=-100) over [B,V,Ld], clip 1.0, AdamW (wd 1e-5 / 0, eps=--adam_epsilon), linear
 schedule), same per-epoch checkpoint dict (:27-42,455-460).  Reference behaviours kept on purpose:
 `model.decoder.embedding` is re-created after construction (:189), which un-ties it from the
@@ -43,12 +44,22 @@ def save_model(path, model, optimizer, scheduler, epoch, best_score=0.0):
 
 def build_parser():
     p = argparse.ArgumentParser()
-    p.add_argument("--data_dir", default='../iaog-dataset', type=str)
-    p.add_argument("--pretrained_data_dir", default='../vimacsa', type=str)
+    # (reference :47-48 marks both `required`; here they are only read by the real-data branch, so --synthetic_steps runs without)
+    p.add_argument("--data_dir", default='../vimacsa', type=str)
+    p.add_argument("--pretrained_data_dir", default='../iaog-pretraining', type=str)
     p.add_argument("--output_dir", default=None, type=str, required=True)
     p.add_argument('--image_dir', default='../vimacsa/image')
     p.add_argument("--pretrained_hf_model", default=None, type=str, required=True)
     p.add_argument("--resume_from_checkpoint", default=None, type=str)
+    # accepted exactly as the reference declares them (run_pretraining_fcmf.py:53,57,60,66,82); --bert_score_model / --beam_size /
+    # --resnet_label_path feed only the reference's commented-out evaluation half (:376-632, dead code there, not built here)
+    p.add_argument('--bert_score_model', default='uitnlp/visobert', type=str,
+                   help="HuggingFace model name or local path for BERTScore (reference: used by its disabled evaluation only)")
+    p.add_argument('--resnet_label_path', default='/kaggle/input/resnet-output')
+    p.add_argument("--max_seq_length", default=170, type=int, help="encoder prompt length (the reference's dataset hard-codes 170)")
+    p.add_argument("--beam_size", default=2, type=int)
+    p.add_argument("--list_aspect", nargs='+', default=[],
+                   help="aspect categories that produce IAOG samples (empty = the six ViMACSA categories, as the reference hard-codes)")
     p.add_argument("--num_imgs", default=7, type=int)
     p.add_argument("--num_rois", default=4, type=int)
     p.add_argument("--max_len_decoder", default=20, type=int)
@@ -141,7 +152,7 @@ def main(argv=None):
 
         def batches():
             for i in range(args.synthetic_steps):
-                b = synth.synth_batch(args.train_batch_size, cfgd, S=min(128, cfg.max_position_embeddings - 2), num_imgs=args.num_imgs, num_roi=args.num_rois,
+                b = synth.synth_batch(args.train_batch_size, cfgd, S=min(args.max_seq_length, 128, cfg.max_position_embeddings - 2), num_imgs=args.num_imgs, num_roi=args.num_rois,
                                       num_aspects=1, seed=args.seed + 1000 * rank + i, coord_dtype=torch.float32)
                 g = torch.Generator().manual_seed(args.seed + i)
                 dec = torch.randint(3, vocab, (args.train_batch_size, args.synthetic_dec_len), generator=g)
@@ -179,7 +190,8 @@ def main(argv=None):
             from feature_cache import FeatureCache
             cache = FeatureCache(args.feature_cache_dir)
         train_ds = IAOGDataset(train_data, tokenizer, args.image_dir, roi_df, dict_image_aspect, dict_roi_aspect,
-                               args.num_imgs, args.num_rois, args.max_len_decoder, feature_cache=cache)
+                               args.num_imgs, args.num_rois, args.max_len_decoder, feature_cache=cache,
+                               max_seq_length=args.max_seq_length, list_aspect=args.list_aspect or None)
         if len(train_ds) == 0:
             raise SystemExit("train_dataset is empty: no 'sentiment_word#Aspect' labels in iaog_labels")
         sampler = DistributedSampler(train_ds) if world > 1 else RandomSampler(train_ds)      # shard once

@@ -101,6 +101,17 @@ def test_iaog_dataset_tuple_layout():
     assert coors[2, 0].tolist() == pytest.approx([1.0, 300 / 512, 100 / 512, 400 / 512])
 
 
+def test_iaog_dataset_honours_max_seq_length_and_list_aspect():
+    """--max_seq_length / --list_aspect of run_pretraining_fcmf.py (reference :60,82) reach the dataset"""
+    from iaog_dataset import IAOGDataset
+    data, roi_df, tags_i, tags_r = _frames()
+    ds = IAOGDataset(data, RecTokenizer(), "/imgs", roi_df, tags_i, tags_r, num_img=1, num_roi=1, max_len_decoder=8,
+                     image_loader=_loader, max_seq_length=96, list_aspect=["Room"])
+    assert [s["target_aspect"] for s in ds.samples] == ["Room"]              # Public_area is not in the list
+    item = ds[0]
+    assert item[5].shape == (96,) and item[8].shape == (96 + 49,) and item[4].shape == (8,)
+
+
 def test_feature_cache_roundtrip(tmp_path):
     from feature_cache import FeatureCache, FeatureCacheWriter
     from vimacsa_dataset import MACSADataset

@@ -104,3 +104,53 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+# The two command lines the reference publishes (argument lists only; paths as printed in the notebooks):
+#   Experimental_Results/Pretraining/Pretraining-Notebook.ipynb:6927-6945  and
+#   Experimental_Results/ViIM_FCMF/ViIM-FCMF-notebook.ipynb:805-825
+PUBLISHED_PRETRAIN = """--data_dir /kaggle/input/vimacsa/ViMACSA --pretrained_data_dir /kaggle/input/iaog-filtered
+ --list_aspect Location Food Room Facilities Service Public_area --num_imgs 7 --num_rois 4
+ --image_dir /kaggle/input/vimacsa/ViMACSA/image --pretrained_hf_model /kaggle/input/uitnlpvisobert/pytorch/default/1
+ --output_dir /kaggle/working/ViMACSA/output/pretraining --train_batch_size 16 --eval_batch_size 64 --num_train_epochs 30
+ --learning_rate 3e-5 --warmup_proportion 0.1 --alpha 1.0 --gradient_accumulation_steps 1 --max_len_decoder 8 --do_train --fp16""".split()
+PUBLISHED_FINETUNE = """--data_dir /kaggle/input/implicit-vimacsa --output_dir /kaggle/working/ViMACSA/output_iaog_fcmf
+ --image_dir /kaggle/input/vimacsa/ViMACSA/image --pretrained_hf_model /kaggle/input/uitnlpvisobert/pytorch/default/1
+ --pretrained_iaog_path /kaggle/input/iaog-last-checkpoint/pytorch/30_epoch/3/seed_42_iaog_model_last.pth
+ --list_aspect Location Food Room Facilities Service Public_area --num_polarity 4 --num_imgs 7 --num_rois 4
+ --train_batch_size 4 --eval_batch_size 32 --num_train_epochs 13 --encoder_learning_rate 7e-5
+ --classifier_head_learning_rate 7e-4 --warmup_proportion 0.1 --gradient_accumulation_steps 2 --do_train --do_eval --fp16
+ --alpha 1""".split()
+# every flag the reference's two parsers declare (run_pretraining_fcmf.py:45-84, run_multimodal_fcmf.py:60-110) with a value of
+# the declared type: the drop-in drivers must accept all of them
+REF_PRETRAIN_FLAGS = {"--data_dir": "d", "--pretrained_data_dir": "p", "--output_dir": "o", "--pretrained_hf_model": "m",
+                      "--bert_score_model": "uitnlp/visobert", "--image_dir": "i", "--resnet_label_path": "r",
+                      "--resume_from_checkpoint": "c", "--max_seq_length": "170", "--max_len_decoder": "20", "--num_imgs": "7",
+                      "--num_rois": "4", "--fine_tune_cnn": None, "--alpha": "0.8", "--beam_size": "2", "--do_train": None,
+                      "--do_eval": None, "--train_batch_size": "8", "--eval_batch_size": "8", "--learning_rate": "3e-5",
+                      "--num_train_epochs": "8.0", "--warmup_proportion": "0.1", "--gradient_accumulation_steps": "1",
+                      "--seed": "42", "--fp16": None, "--adam_epsilon": "1e-8", "--no_cuda": None, "--ddp": None,
+                      "--list_aspect": "Location"}
+
+
+def _argv(flags):
+    out = []
+    for k, v in flags.items():
+        out += [k] if v is None else [k, v]
+    return out
+
+
+def test_drivers_accept_the_published_command_lines():
+    import run_multimodal_fcmf as ft
+    import run_pretraining_fcmf as pt
+    a = pt.build_parser().parse_args(PUBLISHED_PRETRAIN)
+    assert a.list_aspect == ['Location', 'Food', 'Room', 'Facilities', 'Service', 'Public_area']
+    assert (a.max_len_decoder, a.train_batch_size, a.alpha, a.fp16, a.do_train) == (8, 16, 1.0, True, True)
+    # defaults of the flags that command line leaves out are the reference's (run_pretraining_fcmf.py:53-66)
+    assert (a.max_seq_length, a.beam_size, a.bert_score_model, a.resnet_label_path) == (
+        170, 2, 'uitnlp/visobert', '/kaggle/input/resnet-output')
+    b = ft.build_parser().parse_args(PUBLISHED_FINETUNE)
+    assert b.list_aspect[-1] == 'Public_area' and b.num_polarity == 4 and b.gradient_accumulation_steps == 2
+    assert (b.encoder_learning_rate, b.classifier_head_learning_rate, b.alpha) == (7e-5, 7e-4, 1.0)
+    c = pt.build_parser().parse_args(_argv(REF_PRETRAIN_FLAGS))
+    assert c.list_aspect == ['Location'] and c.beam_size == 2 and c.fine_tune_cnn and c.ddp
