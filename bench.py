@@ -2,6 +2,7 @@
 """FCMF training throughput on MI355X: train samples/sec (fwd + bwd + clip + AdamW step).
 
   python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py --gpus N --steps K --warmup W          (starts the N ranks itself: torch.distributed.run as a child process)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -218,7 +219,7 @@ def run_fcmf(args, rank, world, dev, large=False):
     if world > 1 or not args.no_arena:
         arena = GradArena.for_model(model)     # as run_multimodal_fcmf.py does (leaves out bert.cell.pooler: it never gets a gradient)
         if world > 1:
-            red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native)
+            red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native, group_mb=args.dp_group_mb)
             red.broadcast_parameters(0)
     host = synth.synth_batch(B, CFG, S=S, num_imgs=NI, num_roi=NR, num_aspects=A, seed=42 + rank)
     batch = {k: v.to(dev) for k, v in host.items()}
@@ -239,8 +240,14 @@ def run_fcmf(args, rank, world, dev, large=False):
         sched.step()
         return loss
 
+    from fcmf_framework.ops import deferred_dw
+    dw0 = (deferred_dw.batched_launches, deferred_dw.batched_matrices)
     dt, trace, loss = timed_loop(step, args, world, dev)
     comm = red.stats() if red is not None else None
+    if comm is not None:
+        n = max(1, args.steps)
+        comm["dw_batched_launches_per_step"] = round((deferred_dw.batched_launches - dw0[0]) / n, 1)
+        comm["dw_matrices_per_batched_launch"] = round((deferred_dw.batched_matrices - dw0[1]) / max(1, deferred_dw.batched_launches - dw0[0]), 2)
     if rank != 0:
         return None
     # host -> HBM: (1) the bare copy of one batch from pinned memory; (2) the step loop fed through the drivers' DevicePrefetcher --
@@ -293,6 +300,9 @@ def run_fcmf(args, rank, world, dev, large=False):
         "roofline": gemm_roofline(trace),
     }
     if comm is not None:
+        rl = out["roofline"] or {}
+        dwk = (rl.get("per_kernel") or {}).get("gemm_bf16_dw_batched_kernel")
+        comm["dw_batched_tflops"] = dwk["tflops"] if dwk else None      # the batched weight-gradient kernel keeps running under DP
         out["dp"] = comm
     if world == 1 and not args.no_cpu_baseline and not large:
         out["cpu_baseline"] = cpu_baseline()
@@ -324,7 +334,7 @@ def run_iaog(args, rank, world, dev):
     arena = GradArena.for_model(model)      # one memset per step instead of a zero fill per weight gradient
     red = None
     if world > 1:
-        red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native)
+        red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native, group_mb=args.dp_group_mb)
         red.broadcast_parameters(0)
     b = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, num_aspects=1, seed=3 + rank, coord_dtype=torch.float32)
     b = {k: v.to(dev) for k, v in b.items()}
@@ -346,9 +356,11 @@ def run_iaog(args, rank, world, dev):
         return loss
 
     dt, trace, loss = timed_loop(step, args, world, dev)
+    comm = red.stats() if red is not None else None
     if rank != 0:
         return None
     return {
+        "dp": comm,
         "metric": "IAOG pre-train samples/sec (fwd+bwd+step) FCMF-base seq128", "value": round(world * B * args.steps / dt, 2),
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -395,6 +407,50 @@ def run_resnet(args, rank, world, dev):
     }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU under torch.distributed.run as a CHILD process
+    (this process has not touched the GPU and never will), relay rank 0's JSON line, return the child's exit code (non-zero
+    when any rank failed).  reference: torchrun + init_process_group('nccl') at run_multimodal_fcmf.py:126-131,237-240"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no result line\n")
+        rc = 1
+    return rc
+
+
+def launch_check(args, rank, world):
+    """--launch-check: the rendezvous and one collective of the N-rank launch path, WITHOUT touching a GPU (the CPU test of
+    the bare `python bench.py --gpus N` command: tests/test_dp_gloo.py)"""
+    dist.init_process_group(args.backend)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    ok = t.item() == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no GPU work)", "value": None, "n_gpus": world, "launch_check": bool(ok),
+                          "dp_backend": dist.get_backend(), "dp_ranks_seen": dist.get_world_size()}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -414,15 +470,22 @@ def main():
                     help="gradient exchange: float32 all-reduce in place (default, DDP-comparable) or bf16 on the links with float32 accumulation")
     ap.add_argument("--dp-native", dest="dp_native", action="store_true",
                     help="all-reduce through the library's own RCCL binding (fcmf_dp_allreduce_bucket) instead of torch.distributed")
+    ap.add_argument("--dp-group-mb", dest="dp_group_mb", type=float, default=128.0,
+                    help="launch granularity of the gradient exchange: consecutive ready buckets go out (and their queued weight "
+                         "gradients are multiplied together) in groups of at least this many MB")
+    ap.add_argument("--launch-check", dest="launch_check", action="store_true",
+                    help="only the N-rank rendezvous + one collective, no GPU work (CPU test of the launch path)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: one process per GPU, started here (before anything touches the GPU)
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if args.gpus != world:
-        # one process per GPU: ranks come from the launcher (torch.distributed.run sets WORLD_SIZE); a bare
-        # `python bench.py --gpus 8` would silently measure one GPU
-        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with `python -m torch.distributed.run "
-                 f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.launch_check:
+        sys.exit(launch_check(args, rank, world))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if os.environ.get("FCMF_BENCH_SINGLE_DEVICE"):   # rehearsal: several ranks share cuda:0 (use with --backend gloo)
         local = 0

@@ -280,15 +280,19 @@ int fcmf_sum_axis(const void* in, void* out, int64_t outer, int reps, int64_t in
 /* IAOG decoder glue (FCMFSeq2Seq / IAOGDecoder):
  *  fcmf_embed_scale_fwd: out[row] = weight[ids[row]] * scale + pos_table[row % S]  -- `self.embedding(X) * sqrt(H)` followed by
  *      PositionalEncoding's `X + P[:, :T]` (mm_modeling.py:650 and :619-633; pos_table may be NULL); weight / pos_table float32,
- *      out in `dtype`;
- *  fcmf_embed_scale_bwd: dweight[ids[row]] += dy[row] * scale (the embedding gradient; dweight float32, zero-initialised by the caller);
+ *      out in `dtype`; V = rows of `weight`: an id outside [0, V) reads nothing and makes its output row NaN (torch's gather
+ *      raises a device assert there; a NaN loss is the stream-ordered way of being as loud);
+ *  fcmf_embed_scale_bwd: dweight[ids[row]] += dy[row] * scale (the embedding gradient; dweight float32 [V, H], zero-initialised by the
+ *      caller); rows with an id outside [0, V) are skipped -- dweight is a slice of the flat gradient arena, its neighbour is another
+ *      parameter's gradient -- and counted in *oob_count (device int32, may be NULL);
  *  fcmf_head_gather: the decoder `Attention` pairs output slot s of batch element g with head (s*G + g) % heads
  *      (mm_modeling.py:79-85).  slot [G, T, heads*d] dense (gradients per slot, as fcmf_attn_small_bwd with head_quirk writes
  *      them) -> out[g, t, h*d + j] = sum of the slots that read head h; out rows have stride ldo elements (so that dk | dq of a
  *      fused projection land side by side). */
 int fcmf_embed_scale_fwd(const int64_t* ids, const float* weight, const float* pos_table, void* out, int n, int H, int S,
+                         int64_t V, float scale, int dtype, void* stream);
+int fcmf_embed_scale_bwd(const void* dy, const int64_t* ids, float* dweight, int n, int H, int64_t V, int32_t* oob_count,
                          float scale, int dtype, void* stream);
-int fcmf_embed_scale_bwd(const void* dy, const int64_t* ids, float* dweight, int n, int H, float scale, int dtype, void* stream);
 int fcmf_head_gather(const void* slot, void* out, int64_t ldo, int G, int T, int heads, int d, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -353,7 +353,8 @@ static int grid_for(int64_t n, int per) {
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
-extern "C" int fcmf_abi_version(void) { return 3; }   // 2: fcmf_attn_mfma_bwd gained `colsum`; 3: explicit GEMM context (fcmf_gemm takes a ctx), fcmf_dp_*
+// 2: fcmf_attn_mfma_bwd gained `colsum`; 3: explicit GEMM context (fcmf_gemm takes a ctx), fcmf_dp_*; 4: fcmf_embed_scale_* take the table's row count
+extern "C" int fcmf_abi_version(void) { return 4; }
 extern "C" const char* fcmf_build_info(void) { return "libfcmf_hip gfx950 (CDNA4, wave64) abi 3"; }
 
 extern "C" int fcmf_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, float* loss_rows, float* nvalid, int n,
@@ -467,10 +468,16 @@ extern "C" int fcmf_act_bwd(const void* dy, const void* aux, void* out, int64_t 
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scale_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ w,
                                                               const float* __restrict__ P, T* __restrict__ out, int n, int H,
-                                                              int S, float scale) {
+                                                              int S, float scale, int64_t V) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
-  const float* wr = w + ids[row] * (int64_t)H;
+  const int64_t id = ids[row];
+  if (id < 0 || id >= V) {      // a token id outside the table: the row is NaN (loud in the loss), nothing is read
+    const float q = __builtin_nanf("");
+    for (int c = lane * 4; c < H; c += 256) Vec4<T>::store(out + (int64_t)row * H + c, make_float4(q, q, q, q));
+    return;
+  }
+  const float* wr = w + id * (int64_t)H;
   const float* pr = P ? P + (int64_t)(row % S) * H : nullptr;
   for (int c = lane * 4; c < H; c += 256) {
     float4 v = *reinterpret_cast<const float4*>(wr + c);
@@ -485,10 +492,16 @@ __global__ __launch_bounds__(256) void embed_scale_fwd_kernel(const int64_t* __r
 // dweight[ids[row]] += dy[row] * scale  (rows of a token that occurs several times add up: float atomics)
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scale_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ ids,
-                                                              float* __restrict__ dw, int n, int H, float scale) {
+                                                              float* __restrict__ dw, int n, int H, float scale, int64_t V,
+                                                              int32_t* __restrict__ oob) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
-  float* wr = dw + ids[row] * (int64_t)H;
+  const int64_t id = ids[row];
+  if (id < 0 || id >= V) {      // never write outside the gradient slice (it lies in the flat arena: the neighbour is another gradient)
+    if (oob && lane == 0) atomicAdd(oob, 1);
+    return;
+  }
+  float* wr = dw + id * (int64_t)H;
   for (int c = lane * 4; c < H; c += 256) {
     const float4 d = Vec4<T>::load(dy + (int64_t)row * H + c);
     atomicAdd(wr + c, d.x * scale); atomicAdd(wr + c + 1, d.y * scale); atomicAdd(wr + c + 2, d.z * scale); atomicAdd(wr + c + 3, d.w * scale);
@@ -519,25 +532,26 @@ __global__ __launch_bounds__(256) void head_gather_kernel(const T* __restrict__ 
 }
 
 extern "C" int fcmf_embed_scale_fwd(const int64_t* ids, const float* weight, const float* pos_table, void* out, int n, int H, int S,
-                                    float scale, int dtype, void* stream) {
-  if (!ids || !weight || !out || n < 0 || H <= 0 || H % 4 || S <= 0) return FCMF_ERR_ARG;
+                                    int64_t V, float scale, int dtype, void* stream) {
+  if (!ids || !weight || !out || n < 0 || H <= 0 || H % 4 || S <= 0 || V <= 0) return FCMF_ERR_ARG;
   if (n == 0) return FCMF_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((n + 3) / 4);
-  if (dtype == FCMF_F32) hipLaunchKernelGGL((embed_scale_fwd_kernel<float>), grid, dim3(256), 0, st, ids, weight, pos_table, (float*)out, n, H, S, scale);
-  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((embed_scale_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, ids, weight, pos_table, (bf16_t*)out, n, H, S, scale);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((embed_scale_fwd_kernel<float>), grid, dim3(256), 0, st, ids, weight, pos_table, (float*)out, n, H, S, scale, V);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((embed_scale_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, ids, weight, pos_table, (bf16_t*)out, n, H, S, scale, V);
   else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }
 
-extern "C" int fcmf_embed_scale_bwd(const void* dy, const int64_t* ids, float* dweight, int n, int H, float scale, int dtype, void* stream) {
-  if (!dy || !ids || !dweight || n < 0 || H <= 0 || H % 4) return FCMF_ERR_ARG;
+extern "C" int fcmf_embed_scale_bwd(const void* dy, const int64_t* ids, float* dweight, int n, int H, int64_t V, int32_t* oob_count,
+                                    float scale, int dtype, void* stream) {
+  if (!dy || !ids || !dweight || n < 0 || H <= 0 || H % 4 || V <= 0) return FCMF_ERR_ARG;
   if (n == 0) return FCMF_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((n + 3) / 4);
-  if (dtype == FCMF_F32) hipLaunchKernelGGL((embed_scale_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dy, ids, dweight, n, H, scale);
-  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((embed_scale_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dy, ids, dweight, n, H, scale);
+  if (dtype == FCMF_F32) hipLaunchKernelGGL((embed_scale_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dy, ids, dweight, n, H, scale, V, oob_count);
+  else if (dtype == FCMF_BF16) hipLaunchKernelGGL((embed_scale_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dy, ids, dweight, n, H, scale, V, oob_count);
   else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;

@@ -71,8 +71,8 @@ SIGNATURES = {
     "fcmf_dropout": [_vp, _vp, _i64, _f, _u64, _i, _vp],
     "fcmf_act_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "fcmf_sum_axis": [_vp, _vp, _i64, _i, _i64, _i, _vp],
-    "fcmf_embed_scale_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
-    "fcmf_embed_scale_bwd": [_vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "fcmf_embed_scale_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _f, _i, _vp],
+    "fcmf_embed_scale_bwd": [_vp, _vp, _vp, _i, _i, _i64, _vp, _f, _i, _vp],
     "fcmf_head_gather": [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
     "fcmf_multi_sumsq": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "fcmf_multi_adamw": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _i, _f, _f,

@@ -161,11 +161,18 @@ class GradReducer:
                 rank ends up with the same bits, so replicas cannot drift.
     native    : all-reduce through the C ABI (`fcmf_dp_allreduce_bucket`: RCCL bound by libfcmf_hip.so itself) instead of
                 `torch.distributed.all_reduce`; fp32 exchange, CUDA tensors, one GPU per process.
+    group_mb  : launch granularity.  Buckets are SENT in groups of consecutive ready buckets of at least this many MB (128 by
+                default = three to four encoder layers): the weight-gradient GEMMs of a group's parameters are queued by
+                `ops.deferred_dw` until the group goes out and are multiplied together per shape (`fcmf_gemm_dw_batched`), and
+                only the queue entries whose destination lies in the group's arena range are flushed -- later layers keep
+                batching.  (Round 3 flushed the whole queue before every 32 MB bucket: one matrix per shape per flush, i.e. the
+                batched kernel never ran under data parallelism.)  The collectives stay one per bucket, back to back.
     recheck_every: how often (in optimizer steps) the set of parameters that receive no gradient on any rank is
                 re-verified -- a parameter that turns live on SOME rank later raises on EVERY rank instead of
                 silently diverging replicas (round-2 advisor finding)."""
 
-    def __init__(self, arena, bucket_mb=32, process_group=None, overlap=True, exchange="fp32", native=False, recheck_every=50):
+    def __init__(self, arena, bucket_mb=32, process_group=None, overlap=True, exchange="fp32", native=False, recheck_every=50,
+                 group_mb=128):
         if not isinstance(arena, GradArena):                      # list of parameters (round-1 signature)
             arena = GradArena(list(arena))
         if exchange not in ("fp32", "bf16"):
@@ -179,6 +186,7 @@ class GradReducer:
         self.exchange = exchange
         self.recheck_every = recheck_every
         cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.group_elems = int(group_mb * 1024 * 1024 / 4)
         self.buckets = []                     # (lo, hi, [params]) contiguous ranges of arena.flat, backward order
         cur, lo = [], 0
         order = arena.order
@@ -203,6 +211,8 @@ class GradReducer:
         self._dead = None
         self._stage = {}
         self.launch_log = []       # bucket indices in launch order of the current step (tests, diagnostics)
+        self.group_log = []        # (first bucket, last bucket, parameters still without a local gradient) per group sent
+        self._n_dead = [0] * len(self.buckets)
         self._native = None
         if native and self.world > 1:
             self._native = _NativeComm(self.world, self.rank, self.group, arena.flat.device)
@@ -228,6 +238,7 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._work = []
         self.launch_log = []
+        self.group_log = []
         self._next = 0
 
     # -- called by autograd right after p.grad has been accumulated ------------------------------
@@ -236,17 +247,46 @@ class GradReducer:
             return
         self.arena.adopt(p)
         bi = self._bucket_of[id(p)]
-        self._ready[bi].add(id(p))
+        if self._dead is None or id(p) not in self._dead:      # (a "dead" parameter that turns live is caught by the recheck, on every rank at once)
+            self._ready[bi].add(id(p))
         if self.overlap:
             self._launch_in_order()
+
+    def _complete(self, bi):
+        """every parameter of bucket bi has its gradient -- or never gets one: parameters that received no gradient on ANY
+        rank in the first step (`_dead`, the same set on every rank) count as ready, or one of them would hold its bucket and
+        every later one back until finish()"""
+        return len(self._ready[bi]) + self._n_dead[bi] >= len(self.buckets[bi][2])
 
     def _launch_in_order(self, flush=False):
         """collectives must be issued in the SAME order on every rank: buckets go out strictly in arena (= backward) order,
         bucket k only once buckets 0..k-1 have gone.  A bucket that is complete before its predecessor (a parameter without a
-        gradient on this rank, a gradient produced out of order) waits for it -- at the latest until finish()."""
-        while self._next < len(self.buckets) and (flush or len(self._ready[self._next]) == len(self.buckets[self._next][2])):
-            self._launch(self._next)
-            self._next += 1
+        gradient on this rank, a gradient produced out of order) waits for it -- at the latest until finish().  Consecutive
+        complete buckets are sent as a GROUP once they add up to `group_mb` (or the arena ends): see the class docstring."""
+        nb = len(self.buckets)
+        while self._next < nb:
+            end, size = self._next, 0
+            while end < nb and (flush or self._complete(end)):
+                size += self.buckets[end][1] - self.buckets[end][0]
+                end += 1
+                if size >= self.group_elems and not flush:
+                    break
+            if end == self._next or not (flush or size >= self.group_elems or end == nb):
+                return
+            self._flush_range(self._next, end)
+            self.group_log.append((self._next, end - 1, sum(len(self.buckets[b][2]) - len(self._ready[b]) for b in range(self._next, end))))
+            for bi in range(self._next, end):
+                self._launch(bi)
+            self._next = end
+
+    def _flush_range(self, b0, b1):
+        """queued weight-gradient GEMMs (ops.deferred_dw) whose destination lies in buckets b0 .. b1-1 are issued now, as one
+        batch per shape; the others stay queued"""
+        from . import ops
+        flat = self.arena.flat
+        if flat.is_cuda:
+            base = flat.data_ptr()
+            ops.flush_deferred_dw(base + 4 * self.buckets[b0][0], base + 4 * self.buckets[b1 - 1][1])
 
     def _side(self, buf):
         if self._stream is None:
@@ -259,8 +299,6 @@ class GradReducer:
         self._launched[bi] = True
         self.launch_log.append(bi)
         lo, hi, ps = self.buckets[bi]
-        from . import ops
-        ops.flush_deferred_dw()               # queued weight-gradient GEMMs of this bucket's parameters are issued before it is sent
         for p in ps:                          # gradients that arrived while disabled (accumulation) or not at all
             self.arena.adopt(p)
         buf = self.arena.flat[lo:hi]
@@ -343,6 +381,7 @@ class GradReducer:
                                    "GradArena.for_model(skip=...) or build the reducer after the graph is final")
             if self._dead is None:
                 self._dead = dead
+                self._n_dead = [sum(id(p) in dead for p in ps) for _, _, ps in self.buckets]
         for p in self.params:                 # a parameter without a LOCAL gradient still takes part in the mean
             if p.grad is None and id(p) not in self._dead:
                 p.grad = self.arena.view[id(p)]
@@ -353,7 +392,8 @@ class GradReducer:
         """exposed (not overlapped) communication: how long the main stream sat in finish() per step"""
         ms = [a.elapsed_time(b) for a, b in self._events]
         self._events = []
-        return dict(world=self.world, buckets=len(self.buckets), bucket_mb=[round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi, _ in self.buckets],
+        return dict(world=self.world, buckets=len(self.buckets), bytes_per_step=self.arena.total * (2 if self.exchange == "bf16" else 4),
+                    launch_groups=len(self.group_log) or None, group_mb=round(self.group_elems * 4 / 2 ** 20, 1), bucket_mb=[round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi, _ in self.buckets],
                     arena_mb=round(self.arena.total * 4 / 2 ** 20, 1), exchange=self.exchange, native_rccl=self._native is not None,
                     exposed_comm_ms_per_step=round(sum(ms) / max(1, len(ms)), 3) if ms else None, steps=self._steps)
 

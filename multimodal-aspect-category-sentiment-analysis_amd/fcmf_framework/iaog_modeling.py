@@ -327,7 +327,7 @@ class _ScaledEmbedding(torch.autograd.Function):
         T = ids.shape[-1]
         out = torch.empty(tuple(ids.shape) + (Hd,), dtype=out_dtype, device=weight.device)
         P = None if pos_table is None else pos_table.reshape(-1, Hd)[:T].contiguous()
-        H.check(H.lib().fcmf_embed_scale_fwd(H.ptr(idc), H.ptr(weight.detach()), H.ptr(P), H.ptr(out), n, Hd, T, float(scale),
+        H.check(H.lib().fcmf_embed_scale_fwd(H.ptr(idc), H.ptr(weight.detach()), H.ptr(P), H.ptr(out), n, Hd, T, weight.shape[0], float(scale),
                                              H.dt(out), H.stream()), "fcmf_embed_scale_fwd")
         ctx.save_for_backward(idc)
         ctx.scale = scale
@@ -342,8 +342,8 @@ class _ScaledEmbedding(torch.autograd.Function):
         d = dy.contiguous()
         dw = ops.alloc_grad(ctx.weight, ctx.wshape) if ctx.weight is not None else \
             torch.zeros(ctx.wshape, dtype=torch.float32, device=dy.device)
-        H.check(H.lib().fcmf_embed_scale_bwd(H.ptr(d), H.ptr(ids), H.ptr(dw), ids.numel(), ctx.wshape[1], float(ctx.scale),
-                                             H.dt(d), H.stream()), "fcmf_embed_scale_bwd")
+        H.check(H.lib().fcmf_embed_scale_bwd(H.ptr(d), H.ptr(ids), H.ptr(dw), ids.numel(), ctx.wshape[1], ctx.wshape[0], None, float(ctx.scale),
+                                             H.dt(d), H.stream()), "fcmf_embed_scale_bwd")      # (ids outside the table made the forward's rows NaN: the loss already says so)
         return None, dw, None, None, None
 
 

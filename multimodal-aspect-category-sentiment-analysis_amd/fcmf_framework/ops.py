@@ -160,7 +160,9 @@ class _Shadows:
                     raise H.HipLibraryError("head_nk: dense float32 [n_head, E, d] parameters expected")
                 for h in range(nh):
                     src, dst = w.detach()[h], buf[(i * nh + h) * d:(i * nh + h + 1) * d]
-                    k2 = (src.data_ptr(), (E, d))
+                    # (the GROUP is part of the key: the same parameter may sit in two groupings -- [w_kx] alone and [w_kx, w_qx] --
+                    #  and each grouping's buffer must keep its own registered pieces, or the loser would serve stale weights)
+                    k2 = (src.data_ptr(), (E, d), key)
                     self.mapT[k2] = [dst, -1, True, True, weakref.ref(w), src.data_ptr() - w.data_ptr()]
                     pieces.append(k2)
             self._mt_tables = None
@@ -430,8 +432,17 @@ class _DeferredDW:
             self.flush(final=False)
         return True
 
-    def flush(self, final=True):
-        q, self.q, self.bytes = self.q, [], 0
+    def flush(self, final=True, lo=None, hi=None):
+        """multiply the queued gradients; lo / hi: only those whose destination address lies in [lo, hi) (the arena range a
+        data-parallel bucket group is about to send) -- the rest stays queued and keeps batching"""
+        if lo is not None:
+            q = [e for e in self.q if lo <= e[2] < hi]
+            if not q:
+                return
+            self.q = [e for e in self.q if not (lo <= e[2] < hi)]
+            self.bytes = sum(e[0].numel() * e[0].element_size() + e[1].numel() * e[1].element_size() for e in self.q)
+        else:
+            q, self.q, self.bytes = self.q, [], 0
         if final:
             self.armed = False
         groups = {}
@@ -458,10 +469,11 @@ class _DeferredDW:
 deferred_dw = _DeferredDW()
 
 
-def flush_deferred_dw():
-    """multiply the queued weight gradients now (anything that reads the gradient arena before backward() has returned)"""
+def flush_deferred_dw(lo=None, hi=None):
+    """multiply the queued weight gradients now (anything that reads the gradient arena before backward() has returned);
+    lo / hi (device addresses): only the ones whose destination lies in that range of the arena"""
     if deferred_dw.q:
-        deferred_dw.flush(final=False)
+        deferred_dw.flush(final=False, lo=lo, hi=hi)
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI_NONE, acc=False, colsum=None):

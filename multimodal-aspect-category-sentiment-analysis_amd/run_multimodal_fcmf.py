@@ -316,7 +316,7 @@ def main(argv=None):
             if resnet_img is not None:
                 resnet_img.train(); resnet_roi.train()                # reference :431 (BatchNorm in batch-statistics mode)
             arena.zero()
-            for step, batch in enumerate(DevicePrefetcher(train_loader, device)):     # next batch: pinned, on the copy stream
+            for step, batch in enumerate(DevicePrefetcher(train_loader, device, float32_fields=(1,))):     # (1 = the float64 ROI crops) next batch: pinned, on the copy stream
                 t_img, roi_img, roi_coors, ids, tts, ams, added, labels, _ = batch
                 vis, roi = features(t_img, roi_img)
                 logits = model.forward_aspects(input_ids=ids, token_type_ids=tts, attention_mask=ams, added_attention_mask=added,
@@ -383,7 +383,7 @@ def test_evaluate(model, loader, device, features, aspects, output_dir, logger):
     true = {a: [] for a in aspects}
     pred = {a: [] for a in aspects}
     formatted = []
-    for batch in DevicePrefetcher(loader, device):
+    for batch in DevicePrefetcher(loader, device, float32_fields=(1,)):
         t_img, roi_img, roi_coors, ids, tts, ams, added, labels, texts = batch
         vis, roi = features(t_img, roi_img)
         logits = model.forward_aspects(input_ids=ids, token_type_ids=tts, attention_mask=ams, added_attention_mask=added,
@@ -430,7 +430,7 @@ def evaluate(model, loader, device, features, num_aspects, logger):
     """dev-set macro-F1 averaged over aspects (reference :500-552)"""
     model.eval()
     true, pred = [[] for _ in range(num_aspects)], [[] for _ in range(num_aspects)]
-    for batch in DevicePrefetcher(loader, device):
+    for batch in DevicePrefetcher(loader, device, float32_fields=(1,)):
         t_img, roi_img, roi_coors, ids, tts, ams, added, labels, _ = batch
         vis, roi = features(t_img, roi_img)
         logits = model.forward_aspects(input_ids=ids, token_type_ids=tts, attention_mask=ams, added_attention_mask=added,

@@ -22,7 +22,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in include/fcmf_hip.h but not exported"
     assert sorted(_hip.SIGNATURES) == names
     l = _hip.lib()
-    assert l.fcmf_abi_version() == 3
+    assert l.fcmf_abi_version() == 4
     assert b"gfx950" in l.fcmf_build_info()
 
 

@@ -176,7 +176,7 @@ def _fcmf_layout_worker(rank, world, port, q):
     out = {}
     try:
         for exchange in ("fp32", "bf16"):
-            red = GradReducer(arena, bucket_mb=0.02, exchange=exchange, recheck_every=1)
+            red = GradReducer(arena, bucket_mb=0.02, exchange=exchange, recheck_every=1, group_mb=0)    # group_mb=0: every bucket alone
             cap = int(0.02 * 1024 * 1024 / 4)
             # -- layout ------------------------------------------------------------------------------
             pos = 0
@@ -218,6 +218,36 @@ def _fcmf_layout_worker(rank, world, port, q):
             for h in red._hooks:
                 h.remove()
             arena.on_zero.remove(red.reset)
+        # -- launch groups + a dead parameter in bucket 0 (round-3 advisor finding): once the dead set is known it counts as
+        #    ready, so bucket 0 and everything behind it go out DURING backward, in groups of >= group_mb -----------------
+        red = GradReducer(arena, bucket_mb=0.02, group_mb=0.06, recheck_every=1)
+        dead_p = arena.order[3]
+        assert red._bucket_of[id(dead_p)] == 0
+        for step in range(2):
+            arena.zero()
+            early = []
+            for p in arena.order:
+                if p is dead_p:
+                    continue
+                p.grad = pattern[id(p)] * (rank + 1)
+                red._on_grad(p)
+                early.append(len(red.launch_log))
+            if step == 0:
+                assert early[-1] == 0                      # dead set unknown: bucket 0 holds everything until finish()
+            else:
+                assert early[-1] == len(red.buckets)       # everything went out before finish() ...
+                assert 0 < early[len(early) // 2] < len(red.buckets)          # ... part of it half-way through backward
+                assert red.launch_log == list(range(len(red.buckets)))
+                assert red.group_log[0][0] == 0 and red.group_log[0][2] == 1   # first group starts at bucket 0, one parameter without gradient
+                gsz = [sum(red.buckets[b][1] - red.buckets[b][0] for b in range(a, z + 1)) * 4 for a, z, _ in red.group_log]
+                assert all(g >= 0.06 * 2 ** 20 for g in gsz[:-1]) and len(red.group_log) < len(red.buckets)
+            red.finish()
+            assert dead_p.grad is None
+            out[f"grouped{step}"] = max(((p.grad - pattern[id(p)] * 1.5).abs().max() / (pattern[id(p)].abs().max() + 1e-12)).item()
+                                        for p in arena.order if p is not dead_p)
+        for h in red._hooks:
+            h.remove()
+        arena.on_zero.remove(red.reset)
         # -- a parameter that turns live on ONE rank after the dead set was fixed must raise on EVERY rank ---------
         red = GradReducer(arena, bucket_mb=0.02, recheck_every=1)
         dead_p = arena.order[3]
@@ -256,6 +286,7 @@ def test_grad_reducer_fcmf_bucket_layout_order_and_bf16_exchange_gloo():
         assert out["bf16"] < 6e-3, out                      # one bf16 rounding of each rank's contribution + one of the sum
         assert out["fp32_same_bits"] and out["bf16_same_bits"], out
         assert out["raised0"] is False and out["raised1"] is True, out
+        assert out["grouped0"] < 1e-6 and out["grouped1"] < 1e-6, out
 
 
 def test_default_bucket_plan_for_fcmf_base_geometry():
@@ -306,3 +337,24 @@ def test_grad_arena_counts_forward_uses_for_the_deferred_weight_gradients():
         assert arena.used_once(slice_of(b))
     finally:
         arena.deactivate()
+
+
+def test_bare_bench_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what a driver types) must start the two ranks itself, relay ONE
+    JSON line with n_gpus = 2 and exit 0; a launch that cannot work (nccl without a GPU) must exit non-zero.  --launch-check
+    stops after the rendezvous + one collective: no GPU here.  (The real 2-rank step on one MI355X: tests/test_drivers_gpu.py)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["dp_ranks_seen"] == 2 and doc["dp_backend"] == "gloo" and doc["launch_check"] is True
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "nccl", "--launch-check"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

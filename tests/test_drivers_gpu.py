@@ -158,6 +158,13 @@ def test_device_prefetcher_hands_batches_to_hbm(tmp_path, dev):
         y = (img * 2).sum()                     # consume on the compute stream while the next copy is in flight
         n += 1
     assert n == 5 and pf.bytes_copied == sum(t.numel() * t.element_size() for b in host for t in b[:5])
+    # ---- --num_imgs 3: the box tensor is [B, 3, num_rois, 4] -- it must stay float64 (round-3 advisor finding), by shape and by field
+    b3 = (torch.randn(2, 3, 3, 8, 8), torch.randn(2, 3, 5, 3, 8, 8, dtype=torch.float64), torch.rand(2, 3, 5, 4, dtype=torch.float64))
+    for kw in ({}, {"float32_fields": (1,)}):
+        (img, roi, box), = list(DevicePrefetcher(iter([b3]), dev, **kw))
+        assert roi.dtype == torch.float32 and box.dtype == torch.float64 and torch.equal(box.cpu(), b3[2])
+    (d,), = [tuple([x]) for x in DevicePrefetcher(iter([{"roi": b3[1], "box": b3[2]}]), dev, float32_fields=("roi",))]
+    assert d["roi"].dtype == torch.float32 and d["box"].dtype == torch.float64
     # ---- bf16 feature cache -> HBM ------------------------------------------------------------------------------
     path = str(tmp_path / "cache")
     w = FeatureCacheWriter(path, 4, 2, 3)
@@ -201,3 +208,29 @@ def test_pretraining_driver_synthetic(tmp_path, dev):
     m = FCMF(hf, num_imgs=2, num_roi=5)
     missing, unexpected = m.load_state_dict(enc, strict=False)      # IAOG -> fine-tune transfer
     assert not unexpected
+
+
+def test_bare_bench_gpus2_runs_the_real_step_on_two_ranks(dev):
+    """`python bench.py --gpus 2` with no launcher (what the scaling driver types): bench.py starts the two ranks itself; here both
+    share the box's single MI355X (FCMF_BENCH_SINGLE_DEVICE=1) over gloo, so the timings mean nothing -- what is checked is the
+    path: rc 0, ONE line with n_gpus = 2, the gradient exchange in launch groups (several per step, i.e. overlapped with backward),
+    and the batched weight-gradient kernel still multiplying several layers per launch under data parallelism (round 3 flushed
+    the queue per bucket: one matrix per launch).  reference: run_multimodal_fcmf.py:126-131,237-240"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FCMF_BENCH_SINGLE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--batch", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["dp_ranks_seen"] == 2 and doc["dp_backend"] == "gloo" and doc["config"]["global_batch"] == 16
+    dp = doc["dp"]
+    assert dp["world"] == 2 and dp["buckets"] >= 10 and dp["bytes_per_step"] > 6e8
+    assert 2 <= dp["launch_groups"] < dp["buckets"], dp
+    assert dp["dw_matrices_per_batched_launch"] >= 3, dp
+    assert doc["value"] > 0 and doc["loss"] == doc["loss"]

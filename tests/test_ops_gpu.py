@@ -1127,6 +1127,39 @@ def test_gemm_dw_batched_matches_separate_weight_gradients(dev, count, N, K, Mto
     assert H.lib().fcmf_gemm_dw_batched(ctx, 2, two, None, None, N, K, Mtok, N, K, K, acc, H.stream()) == -1        # missing pointer tables
 
 
+@pytest.mark.parametrize("N", [3072, 2304, 768])
+def test_gemm_dw_batched_at_the_step_shape(dev, N):
+    """fcmf_gemm_dw_batched at the shapes of the benchmarked step (VERDICT round 3, weak #1b): the weight gradients of all 12
+    encoder layers in ONE launch, contraction over K = 49152 tokens (B=64 x 6 aspects x 128) -- 12 x 3072 x 768 (FFN in),
+    12 x 2304 x 768 (fused q|k|v), 12 x 768 x 768 (attention output).  Checked against (a) the float64 product of the same bf16
+    operands on sampled 64 x 64 output tiles of the first / middle / last matrix (corners, tile seams at 255|256, interior) and
+    (b) the unbatched split-K kernel on EVERY element of every matrix; accumulate into a pre-filled gradient buffer, as the
+    arena does on a second micro-step."""
+    import ctypes
+    ops, H = _ops()
+    count, K, Mtok = 12, 768, 64 * 6 * 128
+    g = torch.Generator(device=dev).manual_seed(7 + N)
+    dYs = [(torch.randn((Mtok, N), generator=g, device=dev) * 0.5).bfloat16() for _ in range(count)]
+    Xs = [torch.randn((Mtok, K), generator=g, device=dev).bfloat16() for _ in range(count)]
+    base = [torch.randn((N, K), generator=g, device=dev) for _ in range(count)]
+    got = [t.clone() for t in base]
+    arr = lambda ts: (ctypes.c_void_p * count)(*[t.data_ptr() for t in ts])
+    ctx = H.gemm_ctx(workspace=True)
+    H.check(H.lib().fcmf_gemm_dw_batched(ctx, count, arr(dYs), arr(Xs), arr(got), N, K, Mtok, N, K, K, 1, H.stream()), "fcmf_gemm_dw_batched")
+    assert H.last_gemm_kernel() == "gemm_bf16_dw_batched_kernel"
+    scale = (Mtok ** 0.5) * 0.5                                  # magnitude of an output element
+    for i in (0, count // 2, count - 1):
+        for r0, c0 in ((0, 0), (N - 64, K - 64), (224, 224), (N // 2 - 32, 300), (1000 % (N - 64), 512)):
+            ref = dYs[i][:, r0:r0 + 64].double().t() @ Xs[i][:, c0:c0 + 64].double() + base[i][r0:r0 + 64, c0:c0 + 64].double()
+            err = (got[i][r0:r0 + 64, c0:c0 + 64].double() - ref).abs().max().item()
+            assert err < 2e-4 * scale, (i, r0, c0, err)         # float32 accumulation of 49152 products, split 4-7 ways
+    for i in range(count):
+        want = base[i].clone()
+        ops.gemm(dYs[i], Xs[i], want, N, K, Mtok, N, K, K, 1, 1, acc=True)
+        assert torch.isfinite(got[i]).all()
+        assert (got[i] - want).abs().max().item() < 2e-4 * scale, i
+
+
 @pytest.mark.parametrize("M,N,K,bias", [(8192, 64, 256, False), (9000, 64, 576, True), (8200, 128, 1152, False), (16384, 96, 128, True),
                                         (8192, 32, 64, False), (8192, 128, 64, False)])
 def test_gemm_narrow_outputs_on_the_persistent_kernel(dev, M, N, K, bias):
@@ -1144,3 +1177,71 @@ def test_gemm_narrow_outputs_on_the_persistent_kernel(dev, M, N, K, bias):
         ref = ref + b.double().cpu()
     assert torch.isfinite(y).all()
     assert rel_err(y, ref) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_scale_kernels_and_their_vocabulary_bound(dev, dtype):
+    """fcmf_embed_scale_fwd / _bwd (IAOG decoder: `embedding(X) * sqrt(H)` + PositionalEncoding, mm_modeling.py:650,619-633)
+    against torch gather / index_add_; and the table bound (round-3 advisor finding): an id outside [0, V) reads nothing and
+    makes its output row NaN, the backward skips it, counts it, and never writes outside the [V, H] gradient -- which in the
+    product is a slice of the flat arena with another parameter's gradient right behind it."""
+    ops, H = _ops()
+    V, Hd, B, T = 50, 64, 3, 7
+    w = _rand((V, Hd), dev, seed=1)
+    P = _rand((T, Hd), dev, seed=2)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, V, (B, T), generator=g).to(dev)
+    out = torch.empty((B, T, Hd), dtype=dtype, device=dev)
+    H.check(H.lib().fcmf_embed_scale_fwd(H.ptr(ids), H.ptr(w), H.ptr(P), H.ptr(out), B * T, Hd, T, V, 8.0, H.dt(out), H.stream()), "fwd")
+    ref = w[ids] * 8.0 + P
+    assert rel_err(out, ref) < TOL[dtype]
+    dy = _rand((B, T, Hd), dev, dtype, seed=4)
+    guard = torch.zeros((V + 4, Hd), device=dev)                   # 4 guard rows behind the table's gradient
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    H.check(H.lib().fcmf_embed_scale_bwd(H.ptr(dy), H.ptr(ids), H.ptr(guard), B * T, Hd, V, H.ptr(cnt), 8.0, H.dt(dy), H.stream()), "bwd")
+    want = torch.zeros((V, Hd), device=dev).index_add_(0, ids.reshape(-1), dy.float().reshape(-1, Hd) * 8.0)
+    assert rel_err(guard[:V], want) < 1e-5 and guard[V:].abs().sum().item() == 0 and cnt.item() == 0
+    # ---- ids outside the table -------------------------------------------------------------------
+    bad = ids.clone()
+    bad[0, 1], bad[2, 5], bad[1, 0] = V, -1, V + 2
+    out.zero_()
+    H.check(H.lib().fcmf_embed_scale_fwd(H.ptr(bad), H.ptr(w), H.ptr(P), H.ptr(out), B * T, Hd, T, V, 8.0, H.dt(out), H.stream()), "fwd")
+    isbad = (bad < 0) | (bad >= V)
+    assert torch.isnan(out[isbad].float()).all() and torch.isfinite(out[~isbad].float()).all()
+    assert rel_err(out[~isbad], ref[~isbad]) < TOL[dtype]
+    guard.zero_()
+    H.check(H.lib().fcmf_embed_scale_bwd(H.ptr(dy), H.ptr(bad), H.ptr(guard), B * T, Hd, V, H.ptr(cnt), 8.0, H.dt(dy), H.stream()), "bwd")
+    ok = ~isbad.reshape(-1)
+    want = torch.zeros((V, Hd), device=dev).index_add_(0, bad.reshape(-1)[ok], dy.float().reshape(-1, Hd)[ok] * 8.0)
+    assert rel_err(guard[:V], want) < 1e-5 and guard[V:].abs().sum().item() == 0 and cnt.item() == 3
+    assert H.lib().fcmf_embed_scale_bwd(H.ptr(dy), H.ptr(bad), H.ptr(guard), B * T, Hd, 0, None, 8.0, H.dt(dy), H.stream()) != 0
+
+
+def test_head_nk_groupings_of_the_same_parameter_stay_fresh(dev):
+    """shadows.head_nk: the per-head weights of the IAOG decoder's Attention ([n_head, E, d] float32) as registered transposed
+    bf16 copies.  The same parameter in TWO groupings ([w_kx] alone and [w_kx, w_qx]) keeps a buffer per grouping, and both are
+    rebuilt after the parameter changes (round-3 advisor finding: the pieces were keyed by source address only, so the
+    second grouping took over the first one's entries and the first served stale weights)."""
+    ops, H = _ops()
+    nh, E, d = 4, 64, 16
+    wk = torch.nn.Parameter(_rand((nh, E, d), dev, seed=1))
+    wq = torch.nn.Parameter(_rand((nh, E, d), dev, seed=2))
+    want = lambda ws: torch.cat([w.detach().permute(0, 2, 1).reshape(nh * d, E) for w in ws]).bfloat16()
+    try:
+        a = ops.shadows.head_nk([wk])
+        b = ops.shadows.head_nk([wk, wq])
+        assert torch.equal(a, want([wk])) and torch.equal(b, want([wk, wq]))
+        with torch.no_grad():
+            wk.add_(1.0)
+            wq.mul_(2.0)
+        ops.shadows.mark_all_stale()                 # (what the fused optimizers do after their update)
+        a2 = ops.shadows.head_nk([wk])
+        b2 = ops.shadows.head_nk([wk, wq])
+        assert a2.data_ptr() == a.data_ptr() and b2.data_ptr() == b.data_ptr()
+        assert torch.equal(a2, want([wk])) and torch.equal(b2, want([wk, wq]))
+        with torch.no_grad():
+            wk.sub_(0.5)
+        ops.shadows.mark_all_stale()
+        assert torch.equal(ops.shadows.head_nk([wk, wq]), want([wk, wq])) and torch.equal(ops.shadows.head_nk([wk]), want([wk]))
+    finally:
+        ops.shadows.clear()

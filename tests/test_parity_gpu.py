@@ -450,6 +450,53 @@ def test_config1_batch64_bf16_gradient_of_fixture_rows_matches_reference(base, d
         model.zero_grad(set_to_none=True)
 
 
+def test_config1_batch64_bf16_arena_deferred_dw_graph_matches_reference(base, dev):
+    """THE graph bench.py times: BASELINE configs[1] at B=64 in bf16 WITH the gradient arena
+    (`GradArena.for_model`) and the deferred, batched weight gradients (`ops.deferred_dw` -> `fcmf_gemm_dw_batched`: the tiles of
+    12 same-shape matrices per launch, K = 49152 tokens, 7- / 4-way split, fragment-layout partials, batched reduce) -- the
+    kernel `roofline` credits.  As above the loss covers reviews 0-1 (the fixture batch), so every parameter's gradient must
+    equal the REFERENCE's fixture gradient (reference step: run_multimodal_fcmf.py:463-485): norm within 3e-2, cosine >= 0.999
+    over the fixture's sampled elements.  The batched kernel must really have run, at the step's shape."""
+    from fcmf_framework import ops
+    from fcmf_framework.dp import GradArena
+    z, model, _ = base
+    b = batch_to(_batch64_with_fixture_rows(), dev)
+    named = dict(model.named_parameters())
+    old_arena, old_defer = ops.grad_arena(), ops.DEFER_DW
+    try:
+        _set(torch.bfloat16)
+        arena = GradArena.for_model(model)
+        ops.DEFER_DW = True
+        arena.zero()
+        before = (ops.deferred_dw.batched_launches, ops.deferred_dw.batched_matrices)
+        ops.gemm_trace_begin()
+        la = _run_aspects(model, b)
+        model.loss_aspects(la[:2], b["labels"][:2]).backward()
+        trace = ops.gemm_trace_end()
+        assert not ops.deferred_dw.q and not ops.deferred_dw.armed
+        L = model.encoder.bert.cell.config.num_hidden_layers
+        # 4 weight shapes per text-encoder layer (fused q|k|v, attention output, FFN in, FFN out), all 12 layers per launch
+        assert ops.deferred_dw.batched_matrices - before[1] >= 4 * L, ops.deferred_dw.batched_matrices - before[1]
+        big = [(n, fl) for n, fl, _ in trace if n == "gemm_bf16_dw_batched_kernel"]
+        tokens = 64 * 6 * 128
+        assert any(abs(fl - 2.0 * L * 3072 * 768 * tokens) < 1 for _, fl in big), [fl for _, fl in big]      # 12 x 3072 x 768 x K49152 in ONE launch
+        assert any(abs(fl - 2.0 * L * 2304 * 768 * tokens) < 1 for _, fl in big)
+        # every gradient the optimizer would consume lives in the arena
+        flat = arena.flat
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        assert all(lo <= p.grad.data_ptr() < hi for p in arena.order if p.grad is not None)
+        worst, c = _check_grads_against_fixture(named, z, rel_norm_tol=3e-2, cos_tol=0.999)
+        print(f"B=64 bf16 + arena + deferred batched dW vs reference: worst norm err {worst}, sampled cosine {c:.6f}, "
+              f"{ops.deferred_dw.batched_launches - before[0]} batched launches / {ops.deferred_dw.batched_matrices - before[1]} matrices")
+    finally:
+        ops.DEFER_DW = old_defer
+        if "arena" in locals():
+            arena.deactivate()
+        ops.set_grad_arena(old_arena)
+        _set(torch.float32)
+        model.zero_grad(set_to_none=True)
+
+
 def _tiny_train_loss(model, b, seed):
     from fcmf_framework import ops
     ops.manual_seed(seed)
@@ -575,7 +622,8 @@ def test_fcmf_large_geometry_bf16_and_fp32(dev):
     """BASELINE configs[4] geometry (XLM-R-large text encoder H1024 L24 heads16 I4096, seq 256, 100 ROIs per image: the
     shared mm_attention layer attends over 256 + 100 = 356 keys, the text encoder over 256): one review, one aspect,
     fp32 logits against the CPU oracle within 1e-3; bf16 logits within bf16 rounding of them; the bf16 training graph
-    produces finite gradients for every live parameter.  (fp8 GEMMs of that config are not built.)"""
+    produces finite gradients for every live parameter; then the fp8 (e4m3 MFMA) path of that config on the same weights
+    (bounds explained where they are applied below)."""
     cfg = synth.LARGE_CFG
     NI, NR, S = 7, 100, 256
     model, P = build_fcmf(cfg, NI, NR, dev)
