@@ -34,6 +34,9 @@ struct GemmParams {
   // batched weight gradients (gemm_bf16_dw_batched_kernel): the `tiles` output tiles cover `tiles / tiles_per_mat` same-shape
   // matrices, tile t belongs to matrix t / tiles_per_mat whose operand / output pointers come from the BatchPtrs argument
   int tiles_per_mat;
+  // persistent bf16-output kernels: workgroup class c = (blockIdx / 8) & 3 (the workgroups of ONE XCD fall into all four classes)
+  // starts c * phase_ticks x 10 ns late, so that the CUs' epilogue store bursts do not all hit the memory system at once
+  int phase_ticks;
 };
 constexpr int BATCH_MAX = 32;      // matrices per launch (the three pointer tables travel as a kernel argument: 768 bytes)
 struct BatchPtrs { const void* A[BATCH_MAX]; const void* B[BATCH_MAX]; void* C[BATCH_MAX]; };
@@ -634,6 +637,13 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
   };
   constexpr bool PREFETCH = sizeof(TC) == 2;   // bf16 epilogue leaves the ring alone -> next item's tiles 0, 1 fly under it
   bool pre = false;
+  if constexpr (sizeof(TC) == 2) {
+    if (p.phase_ticks > 0) {
+      const unsigned long long late = (unsigned long long)(((blockIdx.x >> 3) & 3) * p.phase_ticks);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__builtin_amdgcn_s_memrealtime() - t0 < late) __builtin_amdgcn_s_sleep(16);
+    }
+  }
 
   for (int item = slot; item < p.total_items; item += nblk) {
   if constexpr (ASM_DMA && sizeof(TC) == 4) {
@@ -1180,6 +1190,146 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
 }
 
 // =========================================================================================
+// 64 x 64 kernel for SMALL outputs (the IAOG decoder: 768 decoder tokens x 768 features x K = 768, ~160 launches per step; the
+// pruned fusion layers of the FCMF step).  On the 128 x 128 kernel such a product is 36 workgroups on 256 CUs, and each of them has to
+// pull 2 x 128 x K x 2 bytes through ONE CU's L2 -> LDS path (~50-70 GB/s): 393 KB = 6-8 us of DMA alone, 20-23 us measured.  Here
+// the tile is 64 x 64 (4 waves, 2 x 2, 32 x 32 outputs each): 144 workgroups that pull 196 KB each, 64-deep k-tiles (whole 128-byte
+// lines per DMA row, half the barriers), the 4-stage ring of the 128 x 128 kernel (three k-tiles in flight), two workgroups per CU.
+// K-contiguous operands only (y = x W^T: every forward and dX GEMM of the bf16 step), K % 64 == 0, no split-K.
+// =========================================================================================
+constexpr int SMALL_T = 64, SMALL_KB = 64, SMALL_TILE_BYTES = SMALL_T * SMALL_KB * 2, SMALL_STAGE_BYTES = 2 * SMALL_TILE_BYTES;
+template <typename TC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_small_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NSTAGE x (A tile + B tile) = 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + SMALL_T - 1) / SMALL_T;
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {   // XCD-aware order (as in the 128 x 128 kernel): the blocks of one XCD walk consecutive tiles, which share the A row panel
+    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int i0 = (bid / tiles_n) * SMALL_T, j0 = (bid % tiles_n) * SMALL_T;
+  const int nkt = p.K / SMALL_KB;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  // an operand tile = 8 pieces of 8 rows x 128 B (the 64-deep image of the big kernels: 16-B chunk c of row r at c ^ ((r >> 1) & 7));
+  // wave w brings pieces 2w, 2w + 1 of both tiles
+  unsigned va[2], vb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    va[j] = dma_voffset_t<false, 64>(wave * 2 + j, lane, p.lda, i0, p.M);
+    vb[j] = dma_voffset_t<false, 64>(wave * 2 + j, lane, p.ldb, j0, p.N);
+  }
+  auto issue = [&](int t) {
+    char* st = smem + (t & (NSTAGE - 1)) * SMALL_STAGE_BYTES + (wave * 2) * 1024;
+    const unsigned kk = (unsigned)t * (SMALL_KB * 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t)(st + j * 1024), 16, va[j], kk, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t)(st + SMALL_TILE_BYTES + j * 1024), 16, vb[j], kk, 0, 0);
+    }
+  };
+  const int rowl = lane & 15, g4 = lane >> 4;
+  const int row_base = rowl * 128 + ((g4 ^ swz_row64(rowl)) << 4);
+  const int a_lane = row_base + wm * 32 * 128, b_lane = row_base + wn * 32 * 128;
+  f32x4 acc[2][2];   // [j frag][i frag]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t)
+    if (t < nkt) issue(t);
+  for (int t = 0; t < nkt; ++t) {
+    const int younger = nkt - 1 - t;     // tile t has landed once at most the DMAs of the (<= 2) younger tiles are outstanding
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + NSTAGE - 1 < nkt) issue(t + NSTAGE - 1);
+    const char* la = smem + (t & (NSTAGE - 1)) * SMALL_STAGE_BYTES;
+    const char* lb = la + SMALL_TILE_BYTES;
+    bf16x8 fa[2][2], fb[2][2];           // [k half][fragment]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        fa[h][f] = *reinterpret_cast<const bf16x8*>(la + (a_lane ^ (h << 6)) + f * 2048);
+        fb[h][f] = *reinterpret_cast<const bf16x8*>(lb + (b_lane ^ (h << 6)) + f * 2048);
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+          acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[h][fj], fa[h][fi], acc[fj][fi], 0, 0, 0);
+  }
+  // ---- epilogue: fragment layout (a lane holds 4 consecutive columns of one row), as in the 128 x 128 kernel ----------------
+  TC* C = reinterpret_cast<TC*>(p.C);
+  TC* AUX = reinterpret_cast<TC*>(p.aux);
+  float4 cs[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+#pragma unroll
+  for (int fi = 0; fi < 2; ++fi) {
+    const int i = i0 + wm * 32 + fi * 16 + (lane & 15);
+    if (i >= p.M) continue;
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj) {
+      const int j = j0 + wn * 32 + fj * 16 + (lane >> 4) * 4;
+      if (j >= p.N) continue;
+      float4 v = make_float4(acc[fj][fi][0], acc[fj][fi][1], acc[fj][fi][2], acc[fj][fi][3]);
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + j);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      const int64_t off = (int64_t)i * p.ldc + j;
+      if (p.epilogue != FCMF_EPI_NONE) {
+        float4 a = make_float4(0, 0, 0, 0);
+        if (p.epilogue == FCMF_EPI_GELU) { if (AUX) Vec4<TC>::store(AUX + off, v); }
+        else if (p.epilogue != FCMF_EPI_TANH) a = Vec4<TC>::load(AUX + off);
+        if constexpr (sizeof(TC) == 2) {
+          v.x = apply_epilogue_fast(v.x, p.epilogue, a.x); v.y = apply_epilogue_fast(v.y, p.epilogue, a.y);
+          v.z = apply_epilogue_fast(v.z, p.epilogue, a.z); v.w = apply_epilogue_fast(v.w, p.epilogue, a.w);
+        } else {
+          v.x = apply_epilogue(v.x, p.epilogue, a.x); v.y = apply_epilogue(v.y, p.epilogue, a.y);
+          v.z = apply_epilogue(v.z, p.epilogue, a.z); v.w = apply_epilogue(v.w, p.epilogue, a.w);
+        }
+      }
+      if constexpr (sizeof(TC) == 4) {
+        float* cf = reinterpret_cast<float*>(C) + off;
+        if (p.accumulate) {
+          float4 o = *reinterpret_cast<float4*>(cf);
+          o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+          *reinterpret_cast<float4*>(cf) = o;
+        } else {
+          *reinterpret_cast<float4*>(cf) = v;
+        }
+      } else {
+        Vec4<TC>::store(C + off, v);
+      }
+      if (p.colsum) { cs[fj].x += v.x; cs[fj].y += v.y; cs[fj].z += v.z; cs[fj].w += v.w; }
+    }
+  }
+  if (p.colsum) {
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj) {
+      float4 t = cs[fj];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64); t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
+      }
+      const int j = j0 + wn * 32 + fj * 16 + (lane >> 4) * 4;
+      if ((lane & 15) == 0 && j < p.N) {
+        atomicAdd(p.colsum + j, t.x); atomicAdd(p.colsum + j + 1, t.y); atomicAdd(p.colsum + j + 2, t.z); atomicAdd(p.colsum + j + 3, t.w);
+      }
+    }
+  }
+}
+
+// =========================================================================================
 // generic kernel: C = op(A) op(B) with arbitrary element strides, f32 MFMA (exact fmaf chains)
 // =========================================================================================
 struct GenericParams {
@@ -1485,6 +1635,7 @@ struct fcmf_gemm_ctx {
   int kb64 = 1;                 // 64-deep k-tiles where they apply
   int num_cus = 256;            // workgroups of the persistent kernels (MI355X: 8 XCDs x 32 CUs, one 160-KiB-LDS workgroup per CU)
   int64_t nt_min_bytes = 0;     // bf16 outputs of at least this many bytes leave with nontemporal stores
+  int phase_ticks = 0;          // start offset between the four workgroup classes of the persistent bf16 kernels, in 10 ns ticks
   char last_kernel[96] = "";
 };
 static const fcmf_gemm_ctx g_default_ctx;    // (const: the defaults of a NULL context)
@@ -1519,6 +1670,11 @@ extern "C" int fcmf_gemm_ctx_tune(fcmf_gemm_ctx* ctx, int force_tile, int kb, in
     ctx->num_cus = num_cus;
   }
   if (nt_min_bytes >= 0) ctx->nt_min_bytes = nt_min_bytes;
+  return FCMF_OK;
+}
+extern "C" int fcmf_gemm_ctx_set_phase(fcmf_gemm_ctx* ctx, int ticks) {
+  if (!ctx || ticks < 0 || ticks > 100000) return FCMF_ERR_ARG;
+  ctx->phase_ticks = ticks;
   return FCMF_OK;
 }
 extern "C" const char* fcmf_gemm_ctx_last_kernel(const fcmf_gemm_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
@@ -1649,6 +1805,7 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
       dim3 grid(p.total_items < slots ? p.total_items : slots);
       p.ws = nullptr;
       p.nt_out = out_dtype == FCMF_BF16 && (int64_t)M * N * 2 >= cfg.nt_min_bytes;
+      p.phase_ticks = (out_dtype == FCMF_BF16 && p.total_items >= 4 * slots) ? cfg.phase_ticks : 0;
       // (partial tiles are whole 256 x 256 fragment-layout tiles when the GEMM has neither bias nor column sums: size by tiles)
       const bool frag_ws = !bias && !colsum;
       const int64_t ws_need = frag_ws ? (int64_t)p.ksplit * tiles_l * GB * GB * 4 : (int64_t)p.ksplit * M * N * 4;
@@ -1685,6 +1842,25 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
     }
     if (colstats) return FCMF_ERR_UNSUPPORTED;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // small outputs (128 x 128 tiles would leave more than half of the CUs without a workgroup): the 64 x 64 kernel
+    if (cfg.force_tile == 0 && cfg.kb64 && !trans_a && !trans_b && !cv && K % 64 == 0 && tiles <= cfg.num_cus / 2 &&
+        (int64_t)M * N >= 64 * 64 && !(accumulate && epilogue == FCMF_EPI_NONE && nk >= 64)) {      // (long-K accumulations: split-K below)
+      p.ksplit = 1; p.ktiles_per_split = K / 64;
+      const dim3 grid(((M + SMALL_T - 1) / SMALL_T) * ((N + SMALL_T - 1) / SMALL_T));
+      const size_t smem = (size_t)NSTAGE * SMALL_STAGE_BYTES;
+      snprintf(last_kernel, NAME, "gemm_bf16_small_kernel<%s>", out_dtype == FCMF_F32 ? "f32" : "bf16");
+      if (out_dtype == FCMF_F32) {
+        auto k = gemm_bf16_small_kernel<float>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(256), smem, st, p);
+      } else {
+        auto k = gemm_bf16_small_kernel<bf16_t>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(256), smem, st, p);
+      }
+      FCMF_CHECK_LAUNCH();
+      return FCMF_OK;
+    }
     int ksplit = 1;
     // split K only where the output grid cannot fill the chip and C is an f32 accumulator
     // (weight gradients: K = number of tokens).

@@ -161,8 +161,8 @@ class GradReducer:
                 rank ends up with the same bits, so replicas cannot drift.
     native    : all-reduce through the C ABI (`fcmf_dp_allreduce_bucket`: RCCL bound by libfcmf_hip.so itself) instead of
                 `torch.distributed.all_reduce`; fp32 exchange, CUDA tensors, one GPU per process.
-    group_mb  : launch granularity.  Buckets are SENT in groups of consecutive ready buckets of at least this many MB (128 by
-                default = three to four encoder layers): the weight-gradient GEMMs of a group's parameters are queued by
+    group_mb  : launch granularity.  Buckets are SENT in groups of consecutive ready buckets of at least this many MB (160 by
+                default = four to five encoder layers): the weight-gradient GEMMs of a group's parameters are queued by
                 `ops.deferred_dw` until the group goes out and are multiplied together per shape (`fcmf_gemm_dw_batched`), and
                 only the queue entries whose destination lies in the group's arena range are flushed -- later layers keep
                 batching.  (Round 3 flushed the whole queue before every 32 MB bucket: one matrix per shape per flush, i.e. the
@@ -172,7 +172,7 @@ class GradReducer:
                 silently diverging replicas (round-2 advisor finding)."""
 
     def __init__(self, arena, bucket_mb=32, process_group=None, overlap=True, exchange="fp32", native=False, recheck_every=50,
-                 group_mb=128):
+                 group_mb=160):
         if not isinstance(arena, GradArena):                      # list of parameters (round-1 signature)
             arena = GradArena(list(arena))
         if exchange not in ("fp32", "bf16"):

@@ -269,18 +269,24 @@ IAOG_SAMPLED = [
     "encoder.mm_attention.layer.0.output.dense.weight", "encoder.box_head.WGs.3.weight"]
 
 
-def iaog_fixture():
-    """IAOG pre-training step (run_pretraining_fcmf.py:186-189,208-212,309-337) at TWO batch sizes: the slot->head
+def iaog_fixture(tag="tiny", cfg=None, Bs=(3, 4), NI=2, NR=5, S=16, Ld=6, col_step=8):
+    """tag "tiny": the tiny geometry (n_head 4, V 512); tag "base" (round 4): the REAL geometry of BASELINE configs[3] -- H 768,
+    12 heads, V 64001, seq 128, Ld 12, 12 decoder blocks -- at B = 3 and B = 5 (different B mod 12 slot->head pairings).
+    IAOG pre-training step (run_pretraining_fcmf.py:186-189,208-212,309-337) at TWO batch sizes: the slot->head
     pairing of the decoder `Attention` depends on B mod n_head (mm_modeling.py:79-85), so B=3 and B=4 (n_head=4)
     exercise different pairings.  Stored per batch size: logits (every 8th column), loss, gradient norms of every
     parameter, sampled gradient elements, the clip norm, and the post-AdamW(wd 1e-5 / 0, lr 3e-5) deltas."""
-    cfg = synth.TINY_CFG
+    cfg = cfg or synth.TINY_CFG
     patch_constants(cfg)
     from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq
     V = cfg["vocab_size"]
-    NI, NR, S, Ld = 2, 5, 16, 6
     out = {}
-    for B in (3, 4):
+    sampled = list(IAOG_SAMPLED)
+    if cfg["num_hidden_layers"] > 2:          # the last decoder block too (the tiny decoder has two)
+        last = cfg["num_hidden_layers"] - 1
+        sampled += [f"decoder.blks.block{last}.attention1.w_kx", f"decoder.blks.block{last}.attention2.w_qx",
+                    f"decoder.blks.block{last}.ffn.dense1.weight", f"encoder.bert.cell.encoder.layer.{last}.output.dense.weight"]
+    for B in Bs:
         hf = make_hf_dir(cfg)
         model = FCMFSeq2Seq(V, 20, hf, NI, NR, 1.0)
         # run_pretraining_fcmf.py:189 -- decoder.embedding is re-created (un-tied) by the driver
@@ -346,7 +352,8 @@ def iaog_fixture():
         names = sorted(grads)
         out[t + "dec"] = dec.numpy()
         out[t + "labels"] = labels.numpy()
-        out[t + "logits"] = logits.detach().numpy()[:, :, ::8]
+        out[t + "logits"] = logits.detach().numpy()[:, :, ::col_step]
+        out[t + "logits_absmax"] = np.float32(logits.detach().abs().max().item())
         out[t + "loss"] = np.float32(loss.item())
         out[t + "cross_attn_nonzero"] = (cross_w[0] > 1e-30).sum(-1).numpy()
         out[t + "total_grad_norm"] = np.float32(float(total_norm))
@@ -355,7 +362,7 @@ def iaog_fixture():
         out[t + "nograd_names"] = np.array(nograd)
         out[t + "delta_norms"] = np.array([(after[n] - before[n]).norm().item() for n in names], dtype=np.float64)
         srng = np.random.Generator(np.random.PCG64(7))
-        for n in IAOG_SAMPLED:
+        for n in sampled:
             g = grads[n].flatten()
             d = (after[n] - before[n]).flatten()
             if g.numel() > 2048:
@@ -371,12 +378,14 @@ def iaog_fixture():
             else:
                 out[t + "g_" + n] = g.numpy()
                 out[t + "d_" + n] = d.numpy()
-    np.savez_compressed(os.path.join(GOLD, "iaog_tiny.npz"), **out)
-    print("iaog fixture ok", os.path.getsize(os.path.join(GOLD, "iaog_tiny.npz")) // 1024, "KiB")
+        del model, opt, Pw, grads, before, after, logits, loss, ol, o_loss
+    out["geometry"] = np.array([NI, NR, S, Ld, col_step])
+    np.savez_compressed(os.path.join(GOLD, f"iaog_{tag}.npz"), **out)
+    print("iaog fixture ok", tag, os.path.getsize(os.path.join(GOLD, f"iaog_{tag}.npz")) // 1024, "KiB")
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["box", "bertadam", "tiny", "iaog", "base"]
+    which = sys.argv[1:] or ["box", "bertadam", "tiny", "iaog", "iaog_base", "base"]
     if "box" in which:
         box_fixture()
     if "bertadam" in which:
@@ -385,5 +394,7 @@ if __name__ == "__main__":
         fcmf_fixture("tiny", synth.TINY_CFG, B=3, S=16, NI=2, NR=5, store_all_grads=False)
     if "iaog" in which:
         iaog_fixture()
+    if "iaog_base" in which:
+        iaog_fixture("base", synth.BASE_CFG, Bs=(3, 5), NI=7, NR=4, S=128, Ld=12, col_step=64)
     if "base" in which:
         fcmf_fixture("base", synth.BASE_CFG, B=2, S=128, NI=7, NR=36, store_all_grads=False)

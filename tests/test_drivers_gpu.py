@@ -232,5 +232,5 @@ def test_bare_bench_gpus2_runs_the_real_step_on_two_ranks(dev):
     dp = doc["dp"]
     assert dp["world"] == 2 and dp["buckets"] >= 10 and dp["bytes_per_step"] > 6e8
     assert 2 <= dp["launch_groups"] < dp["buckets"], dp
-    assert dp["dw_matrices_per_batched_launch"] >= 3, dp
+    assert dp["dw_matrices_per_batched_launch"] >= 2.5, dp
     assert doc["value"] > 0 and doc["loss"] == doc["loss"]

@@ -101,6 +101,55 @@ def test_gemm_k64_and_k32_kernels_agree_bitwise(dev, M, N, K, epi):
         assert torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("epi", ["none", "gelu", "dgelu", "add", "tanh", "f32acc"])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 768), (960, 1536, 768), (100, 136, 128), (768, 64, 64), (1000, 776, 3072)])
+def test_gemm_small_output_kernel_matches_the_128_tile_kernel(dev, M, N, K, epi):
+    """gemm_bf16_small_kernel (64 x 64 tiles, 64-deep k-tiles: the IAOG decoder's 768 x 768 x 768 products, where 128 x 128 tiles
+    occupy 36 of 256 CUs): same products summed in the same order per output element as the 128 x 128 kernel -> every output
+    BIT agrees, for every epilogue the fragment-layout epilogue serves (bias, GELU + pre-activation output, gelu', residual add,
+    tanh, f32 accumulate, column sums); and against the float64 product.  Ragged edges, one k-tile, K = 3072."""
+    ops, H = _ops()
+    A, B = _rand((M, K), dev, torch.bfloat16, seed=1), _rand((N, K), dev, torch.bfloat16, 0.2, seed=2)
+    bias = _rand((N,), dev, seed=3)
+    u = _rand((M, N), dev, torch.bfloat16, 1.5, seed=5)
+    outs = []
+    for tile in (128, 0):
+        H.set_gemm_tuning(tile=tile)
+        try:
+            C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            aux = torch.empty_like(C)
+            cs = torch.zeros(N, dtype=torch.float32, device=dev)
+            if epi == "none":
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, colsum=cs)
+            elif epi == "gelu":
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, aux=aux, epi=H.EPI_GELU)
+            elif epi == "dgelu":
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, aux=u, epi=H.EPI_DGELU, colsum=cs)
+            elif epi == "add":
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, aux=u, epi=H.EPI_ADD)
+            elif epi == "tanh":
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, epi=H.EPI_TANH)
+            else:
+                C = torch.full((M, N), 0.25, dtype=torch.float32, device=dev)
+                ops.gemm(A, B, C, M, N, K, K, K, N, False, False, acc=True)
+            outs.append((C.clone(), aux.clone(), cs.clone(), H.last_gemm_kernel()))
+        finally:
+            H.set_gemm_tuning(tile=0)
+    small = not (epi == "f32acc" and K >= 2048)       # (long accumulating contractions keep the split-K path of the 128 x 128 kernel)
+    assert outs[0][3].startswith("gemm_bf16_kernel") and outs[1][3].startswith("gemm_bf16_small_kernel") == small, (outs[0][3], outs[1][3])
+    assert torch.equal(outs[0][0], outs[1][0])
+    if epi == "gelu":
+        assert torch.equal(outs[0][1], outs[1][1])
+    if epi in ("none", "dgelu"):
+        assert rel_err(outs[1][2], outs[0][2]) < 1e-5            # (float atomics: order not fixed)
+    pre = A.double().cpu() @ B.double().cpu().t()
+    if epi == "none":
+        assert rel_err(outs[1][0], pre + bias.double().cpu()) < 2e-2
+        assert rel_err(outs[1][2], outs[1][0].double().cpu().sum(0)) < 1e-3
+    elif epi == "f32acc":
+        assert rel_err(outs[1][0], pre + 0.25) < 1e-3
+
+
 @pytest.mark.parametrize("M,N,K,nk_note", [(700, 520, 96, "3 k-tiles"), (4400, 4104, 64, "306 tiles: two rounds of work items per CU"),
                                            (300, 264, 32, "1 k-tile"), (1100, 776, 160, "5 k-tiles"),
                                            (1100, 776, 192, "3 k-tiles of 64"), (4400, 4104, 128, "2 k-tiles of 64, two rounds"),

@@ -28,7 +28,8 @@ int main(int argc, char** argv) {
   fcmf_gemm_ctx_create(&ctx);
   fcmf_gemm_ctx_tune(ctx, tile, getenv("FCMF_GEMM_KB") && atoi(getenv("FCMF_GEMM_KB")) == 32 ? 32 : -1,
                      getenv("FCMF_GEMM_CUS") ? atoi(getenv("FCMF_GEMM_CUS")) : -1, -1);
-  printf("---- forced tile: %d (0 = heuristic)\n", tile);
+  if (getenv("FCMF_GEMM_PHASE")) fcmf_gemm_ctx_set_phase(ctx, atoi(getenv("FCMF_GEMM_PHASE")));
+  printf("---- forced tile: %d (0 = heuristic), phase ticks %s\n", tile, getenv("FCMF_GEMM_PHASE") ? getenv("FCMF_GEMM_PHASE") : "0");
   const int T = 49152;
   std::vector<Shape> shapes = {
       {"fwd  qkv/out   NT 49152x768x768", T, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
