@@ -66,7 +66,6 @@ int fcmf_gemm_ctx_create(fcmf_gemm_ctx** ctx);
 int fcmf_gemm_ctx_destroy(fcmf_gemm_ctx* ctx);
 int fcmf_gemm_ctx_set_workspace(fcmf_gemm_ctx* ctx, void* ptr, int64_t bytes);
 int fcmf_gemm_ctx_tune(fcmf_gemm_ctx* ctx, int force_tile, int kb, int num_cus, int64_t nt_min_bytes);
-int fcmf_gemm_ctx_set_phase(fcmf_gemm_ctx* ctx, int ticks);
 const char* fcmf_gemm_ctx_last_kernel(const fcmf_gemm_ctx* ctx);
 
 /* ---------------------------------------------------------------------------------------

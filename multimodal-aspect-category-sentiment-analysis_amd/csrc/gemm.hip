@@ -34,9 +34,6 @@ struct GemmParams {
   // batched weight gradients (gemm_bf16_dw_batched_kernel): the `tiles` output tiles cover `tiles / tiles_per_mat` same-shape
   // matrices, tile t belongs to matrix t / tiles_per_mat whose operand / output pointers come from the BatchPtrs argument
   int tiles_per_mat;
-  // persistent bf16-output kernels: workgroup class c = (blockIdx / 8) & 3 (the workgroups of ONE XCD fall into all four classes)
-  // starts c * phase_ticks x 10 ns late, so that the CUs' epilogue store bursts do not all hit the memory system at once
-  int phase_ticks;
 };
 constexpr int BATCH_MAX = 32;      // matrices per launch (the three pointer tables travel as a kernel argument: 768 bytes)
 struct BatchPtrs { const void* A[BATCH_MAX]; const void* B[BATCH_MAX]; void* C[BATCH_MAX]; };
@@ -637,13 +634,6 @@ __device__ __forceinline__ void gemm_bf16_tile256_body(const GemmParams& p, cons
   };
   constexpr bool PREFETCH = sizeof(TC) == 2;   // bf16 epilogue leaves the ring alone -> next item's tiles 0, 1 fly under it
   bool pre = false;
-  if constexpr (sizeof(TC) == 2) {
-    if (p.phase_ticks > 0) {
-      const unsigned long long late = (unsigned long long)(((blockIdx.x >> 3) & 3) * p.phase_ticks);
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__builtin_amdgcn_s_memrealtime() - t0 < late) __builtin_amdgcn_s_sleep(16);
-    }
-  }
 
   for (int item = slot; item < p.total_items; item += nblk) {
   if constexpr (ASM_DMA && sizeof(TC) == 4) {
@@ -1635,7 +1625,6 @@ struct fcmf_gemm_ctx {
   int kb64 = 1;                 // 64-deep k-tiles where they apply
   int num_cus = 256;            // workgroups of the persistent kernels (MI355X: 8 XCDs x 32 CUs, one 160-KiB-LDS workgroup per CU)
   int64_t nt_min_bytes = 0;     // bf16 outputs of at least this many bytes leave with nontemporal stores
-  int phase_ticks = 0;          // start offset between the four workgroup classes of the persistent bf16 kernels, in 10 ns ticks
   char last_kernel[96] = "";
 };
 static const fcmf_gemm_ctx g_default_ctx;    // (const: the defaults of a NULL context)
@@ -1670,11 +1659,6 @@ extern "C" int fcmf_gemm_ctx_tune(fcmf_gemm_ctx* ctx, int force_tile, int kb, in
     ctx->num_cus = num_cus;
   }
   if (nt_min_bytes >= 0) ctx->nt_min_bytes = nt_min_bytes;
-  return FCMF_OK;
-}
-extern "C" int fcmf_gemm_ctx_set_phase(fcmf_gemm_ctx* ctx, int ticks) {
-  if (!ctx || ticks < 0 || ticks > 100000) return FCMF_ERR_ARG;
-  ctx->phase_ticks = ticks;
   return FCMF_OK;
 }
 extern "C" const char* fcmf_gemm_ctx_last_kernel(const fcmf_gemm_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
@@ -1805,7 +1789,6 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
       dim3 grid(p.total_items < slots ? p.total_items : slots);
       p.ws = nullptr;
       p.nt_out = out_dtype == FCMF_BF16 && (int64_t)M * N * 2 >= cfg.nt_min_bytes;
-      p.phase_ticks = (out_dtype == FCMF_BF16 && p.total_items >= 4 * slots) ? cfg.phase_ticks : 0;
       // (partial tiles are whole 256 x 256 fragment-layout tiles when the GEMM has neither bias nor column sums: size by tiles)
       const bool frag_ws = !bias && !colsum;
       const int64_t ws_need = frag_ws ? (int64_t)p.ksplit * tiles_l * GB * GB * 4 : (int64_t)p.ksplit * M * N * 4;

@@ -41,7 +41,6 @@ SIGNATURES = {
     "fcmf_gemm_ctx_destroy": [_vp],
     "fcmf_gemm_ctx_set_workspace": [_vp, _vp, _i64],
     "fcmf_gemm_ctx_tune": [_vp, _i, _i, _i, _i64],
-    "fcmf_gemm_ctx_set_phase": [_vp, _i],
     "fcmf_gemm_ctx_last_kernel": [_vp],
     "fcmf_quant_fp8_rows": [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp],
     "fcmf_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _vp],
@@ -168,14 +167,12 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda id
 SPLITK_WORKSPACE_BYTES = 512 << 20   # >= ksplit*M*N*4 of every weight-gradient GEMM of FCMF-base (66 MB for 768x768 x 28 splits)
 _gemm_ctx = {}
 _gemm_tuning = dict(tile=int(os.environ.get("FCMF_GEMM_TILE", "0")), kb=32 if os.environ.get("FCMF_GEMM_KB") == "32" else 64,
-                    cus=int(os.environ.get("FCMF_GEMM_CUS", "256")), nt_min_mb=int(os.environ.get("FCMF_GEMM_NT_MIN_MB", "0")),
-                    phase=int(os.environ.get("FCMF_GEMM_PHASE", "0")))
+                    cus=int(os.environ.get("FCMF_GEMM_CUS", "256")), nt_min_mb=int(os.environ.get("FCMF_GEMM_NT_MIN_MB", "0")))
 
 
 def _apply_tuning(h):
     t = _gemm_tuning
     check(lib().fcmf_gemm_ctx_tune(h, t["tile"], t["kb"], t["cus"], t["nt_min_mb"] << 20), "fcmf_gemm_ctx_tune")
-    check(lib().fcmf_gemm_ctx_set_phase(h, t["phase"]), "fcmf_gemm_ctx_set_phase")
 
 
 def gemm_ctx(workspace=False):
@@ -194,9 +191,9 @@ def gemm_ctx(workspace=False):
     return ent[0]
 
 
-def set_gemm_tuning(tile=None, kb=None, cus=None, nt_min_mb=None, phase=None):
-    """benchmark / test knobs (see fcmf_gemm_ctx_tune / fcmf_gemm_ctx_set_phase), applied to every existing and future context"""
-    for k, v in (("tile", tile), ("kb", kb), ("cus", cus), ("nt_min_mb", nt_min_mb), ("phase", phase)):
+def set_gemm_tuning(tile=None, kb=None, cus=None, nt_min_mb=None):
+    """benchmark / test knobs (see fcmf_gemm_ctx_tune), applied to every existing and future context"""
+    for k, v in (("tile", tile), ("kb", kb), ("cus", cus), ("nt_min_mb", nt_min_mb)):
         if v is not None:
             _gemm_tuning[k] = int(v)
     for h, _ in _gemm_ctx.values():

@@ -121,3 +121,29 @@ def test_oracle_iaog_tiny(B):
                 g = g[torch.from_numpy(z[t + "gidx_" + n])]
             ref = torch.from_numpy(z[key])
             assert (g - ref).abs().max().item() < 1e-4 * max(ref.abs().max().item(), 1e-6), n
+
+
+def test_oracle_iaog_base_geometry_forward():
+    """the oracle at IAOG's REAL geometry (H 768, 12 heads, V 64001, seq 128, Ld 12, 12 decoder blocks, B = 5: slot -> head pairing
+    (s * 5 + b) mod 12) against the reference fixture iaog_base.npz: logits and loss (forward only here -- make_golden.py
+    checked the gradients against the reference import when it wrote the fixture; the GPU test checks the product's)"""
+    z = np.load(os.path.join(GOLD, "iaog_base.npz"))
+    B, t = 5, "b5_"
+    cfg = synth.BASE_CFG
+    V = cfg["vocab_size"]
+    NI, NR, S, Ld, step = (int(x) for x in z["geometry"])
+    shapes = {k: v for k, v in synth.fcmf_param_shapes(cfg).items() if k.startswith("encoder.")}
+    shapes.update(synth.iaog_decoder_param_shapes(cfg, V))
+    P = synth.synth_params(shapes)
+    P["decoder.dense.weight"] = P["encoder.bert.cell.embeddings.word_embeddings.weight"]
+    batch = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, seed=5, coord_dtype=torch.float32)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        enc = O.fcmf_encoder_forward(P, cfg, batch["input_ids"][:, 0], batch["visual_embeds_att"],
+                                     batch["roi_embeds_att"], batch["roi_coors"], batch["token_type_ids"][:, 0],
+                                     batch["attention_mask"][:, 0], batch["added_attention_mask"][:, 0], NI, NR)
+        logits = O.iaog_decoder_forward(P, cfg, torch.from_numpy(z[t + "dec"]), enc)
+        assert tuple(logits.shape) == (B, Ld, V)
+        assert (logits[:, :, ::step] - torch.from_numpy(z[t + "logits"])).abs().max() < 1e-4
+        loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), torch.from_numpy(z[t + "labels"]), ignore_index=-100)
+    assert abs(loss.item() - float(z[t + "loss"])) < 1e-4

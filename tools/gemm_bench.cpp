@@ -27,9 +27,9 @@ int main(int argc, char** argv) {
   fcmf_gemm_ctx* ctx = nullptr;
   fcmf_gemm_ctx_create(&ctx);
   fcmf_gemm_ctx_tune(ctx, tile, getenv("FCMF_GEMM_KB") && atoi(getenv("FCMF_GEMM_KB")) == 32 ? 32 : -1,
-                     getenv("FCMF_GEMM_CUS") ? atoi(getenv("FCMF_GEMM_CUS")) : -1, -1);
-  if (getenv("FCMF_GEMM_PHASE")) fcmf_gemm_ctx_set_phase(ctx, atoi(getenv("FCMF_GEMM_PHASE")));
-  printf("---- forced tile: %d (0 = heuristic), phase ticks %s\n", tile, getenv("FCMF_GEMM_PHASE") ? getenv("FCMF_GEMM_PHASE") : "0");
+                     getenv("FCMF_GEMM_CUS") ? atoi(getenv("FCMF_GEMM_CUS")) : -1,
+                     getenv("FCMF_GEMM_NT_MIN_MB") ? ((int64_t)atoi(getenv("FCMF_GEMM_NT_MIN_MB")) << 20) : -1);
+  printf("---- forced tile: %d (0 = heuristic)\n", tile);
   const int T = 49152;
   std::vector<Shape> shapes = {
       {"fwd  qkv/out   NT 49152x768x768", T, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
@@ -118,25 +118,25 @@ int main(int argc, char** argv) {
     if (hog) hipStreamSynchronize(hs);
     double tf = 2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12;
     printf("%-40s rc=%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 2500)\n", sh.name, rc, ms, tf, tf / 25.0);
-    // diagnostic library (make timing; LD_LIBRARY_PATH=tools/bin/timing): per-phase stamps of workgroup 0
-    typedef void (*tb_fn)(void*);
-    static tb_fn set_buf = (tb_fn)dlsym(RTLD_DEFAULT, "fcmf_gemm_timing_buffer");
-    if (set_buf) {
-      static unsigned long long* dbuf = nullptr;
-      if (!dbuf) hipMalloc(&dbuf, 16 * 8 * 8);
-      hipMemset(dbuf, 0, 16 * 8 * 8);
-      set_buf(dbuf);
+    // diagnostic library (python tools/diag/make_gemm_diag.py; LD_LIBRARY_PATH=tools/bin/diag): phase stamps of workgroup 8, waves 0 / 4
+    typedef int (*rd_fn)(void*, int);
+    static rd_fn rd = (rd_fn)dlsym(RTLD_DEFAULT, "fcmf_gemm_diag_read");
+    if (rd) {
+      static unsigned long long h[2 * 16 * 16];
+      rd(h, 1);                      // clear what the timed launches left
       run();
       hipDeviceSynchronize();
-      set_buf(nullptr);
-      unsigned long long h[128];
-      hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
-      printf("    item: fill  loop(8kt..end)  ->barrier  finish  stores | total   [us, 100 MHz stamps, workgroup 0 wave 0]\n");
-      for (int it = 0; it < 10 && h[it * 8 + 5]; ++it) {
-        auto d = [&](int a, int b2) { return (double)(long long)(h[it * 8 + b2] - h[it * 8 + a]) * 0.01; };
-        printf("    %4d: %5.2f %5.2f+%5.2f %5.2f %5.2f %5.2f | %6.2f   loop clock %.0f MHz (s_memtime / s_memrealtime)\n", it, d(0, 1), d(1, 6), d(6, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 5),
-               (double)h[it * 8 + 7] / d(1, 2));
-      }
+      rd(h, 0);
+      printf("    wave item:   loop  (waits: sum  t0  t1  t2)   prefetch  epilogue | item total   [us at the measured shader clock]\n");
+      for (int g = 0; g < 2; ++g)
+        for (int it = 0; it + 1 < 16 && h[(g * 16 + it + 1) * 16]; ++it) {
+          const unsigned long long* r = &h[(g * 16 + it) * 16];
+          const unsigned long long* n = &h[(g * 16 + it + 1) * 16];
+          const double mhz = (double)(n[0] - r[0]) / ((double)(n[8] - r[8]) * 0.01);      // cycles per us
+          auto us = [&](unsigned long long c) { return (double)c / mhz; };
+          printf("    %4d %4d: %6.2f (%5.2f %5.2f %5.2f %5.2f)  %5.2f  %6.2f | %6.2f   clock %.0f MHz\n", g * 4, it, us(r[1] - r[0]), us(r[4]), us(r[5]), us(r[6]),
+                 us(r[7]), us(r[2] - r[1]), us(r[3] - r[2]), us(n[0] - r[0]), mhz);
+        }
     }
   }
   return 0;

@@ -7,6 +7,8 @@
 //   1  "row-512":    the wave owns 32 full tile rows (256 columns = 512 B) and stores 2 rows x 512 B
 //   2  "row-1k":     tiles are 128 rows x 512 columns, the wave stores 1 row x 1 KiB
 //   3  "linear":     no tiling: each wave streams contiguous KiBs (upper bound)
+//   4  "frag-64":    the wave's 128 x 64 sub-tile, 16 rows x 64 B per instruction (lane = (row & 15, 16-B piece of a 64-B half line):
+//                    what a store straight from permuted accumulator fragments would issue -- no LDS transposition)
 // each with plain and with nt (aux = 2) stores; optional `gap_us` of ALU spin between tiles to mimic the main loop (burstiness).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -51,6 +53,11 @@ __global__ __launch_bounds__(512, 1) void store_kernel(void* out, int M, int N, 
       const unsigned base = (unsigned)(i0 + wm * 128 + (lane >> 3)) * ld + (unsigned)(j0 + wn * 64 + (lane & 7) * 8) * 2u;
 #pragma unroll 4
       for (int it = 0; it < 16; ++it) st(base + (unsigned)(it * 8) * ld);
+    } else if (PAT == 4) {
+      const int wm = wave >> 2, wn = wave & 3;
+      const unsigned base = (unsigned)(i0 + wm * 128 + (lane & 15)) * ld + (unsigned)(j0 + wn * 64 + (lane >> 4) * 8) * 2u;
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) st(base + (unsigned)((it >> 1) * 16) * ld + (unsigned)(it & 1) * 64u);
     } else if (PAT == 1) {
       const unsigned base = (unsigned)(i0 + wave * 32 + (lane >> 5)) * ld + (unsigned)(j0 + (lane & 31) * 8) * 2u;
 #pragma unroll 4
@@ -92,6 +99,8 @@ int main(int argc, char** argv) {
     for (int gap : {0, 1000, 2500}) {
       run<0, false>("wave-slice", out, M, N, gap, reps);
       run<0, true>("wave-slice", out, M, N, gap, reps);
+      run<4, false>("frag-64", out, M, N, gap, reps);
+      run<4, true>("frag-64", out, M, N, gap, reps);
       run<1, false>("row-512", out, M, N, gap, reps);
       run<1, true>("row-512", out, M, N, gap, reps);
       if (N % 512 == 0) {
