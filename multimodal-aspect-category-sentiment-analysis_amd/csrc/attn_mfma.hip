@@ -24,8 +24,12 @@ constexpr int TILE_B = AT * AD * 2;  // 16 KiB
 // [rows][64 bf16] tile, 128-B rows: 32-B pair index XOR ((r>>1)&1 | ((r>>3)&1)<<1)
 __device__ __forceinline__ int vkey(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
 __device__ __forceinline__ int off64(int r, int c8) { return r * 128 + ((((c8 >> 1) ^ vkey(r))) << 5) + ((c8 & 1) << 4); }
-// [128][128 bf16] tile, 256-B rows, 16-B chunk XOR ((r&3)<<2 | (r>>2)&3)
-__device__ __forceinline__ int key16(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+// [32 keys][128 q bf16] chunk images of the backward (Pdrop^T, dS^T), 256-B rows: 16-B chunk XOR key16(row & 15), a GF(2)-linear key
+// (bit columns 2, 4, 8, 9) under which BOTH read patterns are conflict free -- the ds_read_b128 operand reads of phase 2 (row = lane & 15,
+// chunk = 4 s + (lane >> 4)) and the ds_read_b64_tr_b16 reads of dS^T (tools/lds_conflicts.py searches the 4 x 4 bit matrices; the
+// ds_write_b64 of phase 1 puts 16 rows of one column into a 128-B bank window and is 2-way under any key).  The round-3 key
+// ((r & 3) << 2 | (r >> 2) & 3) left every operand read 2-way: 30 % of the kernel's LDS cycles were bank conflicts (r03_attn_pmc.txt).
+__device__ __forceinline__ int key16(int r) { return ((r & 7) << 1) ^ (((r >> 3) & 1) * 9); }
 __device__ __forceinline__ int off128(int r, int ch) { return r * 256 + ((ch ^ key16(r)) << 4); }
 // per-wave P tile of the forward [32][128 bf16]: chunk XOR (row & 15)
 __device__ __forceinline__ int offp(int r, int ch) { return r * 256 + ((ch ^ (r & 15)) << 4); }

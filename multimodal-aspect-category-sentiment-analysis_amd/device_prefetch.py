@@ -23,7 +23,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
-_COPY_THREADS = 4
+_COPY_THREADS = 8
 _PARALLEL_MIN_BYTES = 8 << 20
 
 

@@ -42,27 +42,38 @@ if __name__ == "__main__":
                     a.append(off(32 * s + 8 * g4 + q4 + hi, 2 * df + (p >> 1)) + (p & 1) * 8)
                 assert read_tr_b64(a) == 1, ("tr read", s, df, hi, read_tr_b64(a))
     print("128B-row dual swizzle: row reads and tr reads conflict free")
-    # ---- 256-byte-row tile [128][128 bf16], form (b): ch ^ (((row&3)<<2)|((row>>2)&3)) ------------
-    k16 = lambda r: ((r & 3) << 2) | ((r >> 2) & 3)
-    offb = lambda r, ch: r * 256 + ((ch ^ k16(r)) << 4)
-    worst_row = worst_tr = worst_w = 1
-    for s in range(4):
-        for f in range(8):
-            worst_row = max(worst_row, read_b128([offb(16 * f + (l & 15), 4 * s + (l >> 4)) for l in range(64)]))
-    for s in range(4):
-        for c0 in range(0, 16, 2):
+    # ---- attention backward (csrc/attn_mfma.hip): chunk images Pdrop^T / dS^T [32 keys][128 q bf16], 256-B rows, 16-B chunk ^ key16(row & 15).
+    #      Access patterns of the kernel:  phase-1 writes (ds_write_b64: row 16 k4 + (lane & 15), chunk 4 w + 2 f + (lane >> 5), half (lane >> 4) & 1),
+    #      phase-2 operand reads (ds_read_b128: row 16 kf + (lane & 15), chunk 4 s + (lane >> 4)) and the transposed reads of dS^T
+    #      (ds_read_b64_tr_b16: row 8 g + q (+4), chunk 4 w + 2 f + (p >> 1), half p & 1).
+    def chunk_image(key):
+        offb = lambda r, ch: r * 256 + ((ch ^ key(r & 15)) << 4)
+        row = max(read_b128([offb(16 * kf + (l & 15), 4 * s + (l >> 4)) for l in range(64)]) for kf in range(2) for s in range(4))
+        tr = 1
+        for c0 in range(0, 128, 16):
             for hi in (0, 4):
                 a = []
                 for l in range(64):
                     g4, i16 = l >> 4, l & 15
                     q4, p = i16 >> 2, i16 & 3
-                    a.append(offb(32 * s + 8 * g4 + q4 + hi, c0 + (p >> 1)) + (p & 1) * 8)
-                worst_tr = max(worst_tr, read_tr_b64(a))
-    for kf in range(8):
-        for ch0 in range(0, 16, 2):
-            a = [offb(16 * kf + (l & 15), ch0 + (l >> 5)) + ((l >> 4) & 1) * 8 for l in range(64)]
-            worst_w = max(worst_w, write_b64(a))
-    print("256B-row form (b): row read", worst_row, "way; tr read", worst_tr, "way; b64 write", worst_w, "way")
+                    a.append(offb(8 * g4 + q4 + hi, (c0 >> 3) + (p >> 1)) + (p & 1) * 8)
+                tr = max(tr, read_tr_b64(a))
+        wr = max(write_b64([offb(16 * k4 + (l & 15), 4 * w + 2 * f + (l >> 5)) + ((l >> 4) & 1) * 8 for l in range(64)])
+                 for w in range(4) for f in range(2) for k4 in range(2))
+        return row, tr, wr
+    old_key = lambda r: ((r & 3) << 2) | ((r >> 2) & 3)
+    new_key = lambda r: ((r & 7) << 1) ^ (((r >> 3) & 1) * 9)
+    print("attention backward chunk images, round-3 key: (row read, tr read, b64 write) ways =", chunk_image(old_key))
+    print("attention backward chunk images, round-4 key: (row read, tr read, b64 write) ways =", chunk_image(new_key))
+    assert chunk_image(new_key) == (1, 1, 2)
+    if "--search" in __import__("sys").argv:      # all GF(2)-linear keys with conflict-free reads
+        import itertools
+        found = []
+        for cols in itertools.product(range(16), repeat=4):
+            key = lambda r, c=cols: (c[0] * (r & 1)) ^ (c[1] * ((r >> 1) & 1)) ^ (c[2] * ((r >> 2) & 1)) ^ (c[3] * ((r >> 3) & 1))
+            if len({key(r) for r in range(16)}) == 16 and chunk_image(key)[:2] == (1, 1):
+                found.append(cols)
+        print(len(found), "linear keys with conflict-free reads, e.g.", found[:4])
     # ---- P tile of the forward: [32 q][128 keys] rows 256 B, ch ^ (row & 15) -------------------
     offp = lambda r, ch: r * 256 + ((ch ^ (r & 15)) << 4)
     wr = max(read_b128([offp(16 * f + (l & 15), 4 * s + (l >> 4)) for l in range(64)]) for s in range(4) for f in range(2))
