@@ -121,6 +121,28 @@ class GradArena:
         self._taken.add(id(p))
         return self.view[id(p)]
 
+    def retake(self, param):
+        """the slice of `param` if an EARLIER producer of this backward pass has already claimed it (a weight applied several
+        times in the forward: the fusion layer runs 7 + 1 times): the caller accumulates into it IN PLACE and hands autograd
+        `None` for this use -- the first producer's tensor, which autograd holds until every use has reported, is this very
+        memory.  (Round 3 gave later producers a zero-filled temporary that autograd then added: a fill and an add launch per
+        parameter and use.)  Not across micro-steps: once p.grad is set, the first producer of a pass must return a tensor, or
+        the post-accumulate hook that drives the bucket exchange would not fire."""
+        p = self._by_ptr.get(param.data_ptr())
+        if p is None or p.numel() != param.numel() or id(p) not in self._taken or p.grad is not None:
+            return None
+        return self.view[id(p)]
+
+    def retake_block(self, params):
+        ps = [self._by_ptr.get(q.data_ptr()) for q in params]
+        if any(p is None or id(p) not in self._taken or p.grad is not None for p in ps):
+            return None
+        off = self.offset[id(ps[0])]
+        for a, b in zip(ps, ps[1:]):
+            if self.offset[id(b)] != self.offset[id(a)] + a.numel():
+                return None
+        return self.flat[off:off + sum(p.numel() for p in ps)]
+
     def take_block(self, params):
         """one tensor covering the adjacent slices of `params` (or None)"""
         ps = [self._by_ptr.get(q.data_ptr()) for q in params]

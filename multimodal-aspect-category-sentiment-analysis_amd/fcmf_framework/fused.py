@@ -268,15 +268,23 @@ def _grad_arena(device, Hd, I, with_qkv, params=None):
     if with_qkv:
         sizes = [("wqkv", (3 * Hd, Hd)), ("bqkv", (3 * Hd,))] + sizes
     arena = ops.grad_arena() if params is not None else None
-    out = {}
+    out = {"_inplace": set()}       # names whose buffer is the slice an EARLIER use of the same (shared) parameter returned: autograd gets None
     if arena is not None:
         for n, s in sizes:
             q = params.get(n)
             v = None
             if isinstance(q, (list, tuple)):
                 v = arena.take_block(q)
+                if v is None:
+                    v = arena.retake_block(q)
+                    if v is not None:
+                        out["_inplace"].add(n)
             elif q is not None:
                 v = arena.take(q)
+                if v is None:
+                    v = arena.retake(q)
+                    if v is not None:
+                        out["_inplace"].add(n)
             if v is not None:
                 out[n] = v.view(s)
         sizes = [(n, s) for n, s in sizes if n not in out]
@@ -315,8 +323,9 @@ class PostAttentionFn(torch.autograd.Function):
         side = _SideGemms(c2.device)
         dc, dres = _post_bwd(dy.reshape(c2.shape).contiguous(), c2, saved, wo, w1, w2, g1, g2, p, (s0, s1), G, side)
         side.join()
-        return (dc.view(cshape), dres.view(rshape), G["wo"], G["bo"], G["g1"], G["be1"], G["w1"], G["b1"], G["w2"], G["b2"],
-                G["g2"], G["be2"], None, None, None, None)
+        r = lambda n: None if n in G["_inplace"] else G[n]      # (accumulated in place: see dp.GradArena.retake)
+        return (dc.view(cshape), dres.view(rshape), r("wo"), r("bo"), r("g1"), r("be1"), r("w1"), r("b1"), r("w2"), r("b2"),
+                r("g2"), r("be2"), None, None, None, None)
 
 
 class SelfLayerFn(torch.autograd.Function):
@@ -362,6 +371,9 @@ class SelfLayerFn(torch.autograd.Function):
         side.launch((dqkv, x2), dqkv, x2, G["wqkv"], 3 * Hd, Hd, M, 3 * Hd, Hd, Hd, 1, 1, acc=True)
         side.join()
         W, b = G["wqkv"], G["bqkv"]
-        return (dx.view(xshape), None, W[:Hd], b[:Hd], W[Hd:2 * Hd], b[Hd:2 * Hd], W[2 * Hd:], b[2 * Hd:], G["wo"], G["bo"],
-                G["g1"], G["be1"], G["w1"], G["b1"], G["w2"], G["b2"], G["g2"], G["be2"],
+        r = lambda n: None if n in G["_inplace"] else G[n]      # (accumulated in place: see dp.GradArena.retake)
+        Ws = (None, None, None) if "wqkv" in G["_inplace"] else (W[:Hd], W[Hd:2 * Hd], W[2 * Hd:])
+        bs = (None, None, None) if "bqkv" in G["_inplace"] else (b[:Hd], b[Hd:2 * Hd], b[2 * Hd:])
+        return (dx.view(xshape), None, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2], r("wo"), r("bo"),
+                r("g1"), r("be1"), r("w1"), r("b1"), r("w2"), r("b2"), r("g2"), r("be2"),
                 None, None, None, None, None, None, None)

@@ -13,8 +13,10 @@ from . import ops
 def additive_mask(mask01, length, value=-10000.0):
     """(1 - mask[:, :length]) * value as float32 [G, length]  (fcmf_pretraining.py:53-56,97-100,133-136;
     value = finfo(float32).min for the HF text encoder)"""
-    m = mask01[:, :length].to(torch.float32)
-    return (1.0 - m) * value
+    m = mask01[:, :length]
+    if m.dtype.is_floating_point:
+        return (1.0 - m.to(torch.float32)) * value
+    return (m - 1) * (-float(value))        # integer 0 / 1 masks: the same values ((1 - m) * value exactly) in two launches instead of three
 
 
 def attn_sublayer_params(mod):

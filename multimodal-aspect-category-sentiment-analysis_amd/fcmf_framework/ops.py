@@ -309,6 +309,23 @@ def alloc_grad(param, shape=None):
     return torch.zeros(tuple(param.shape) if shape is None else shape, dtype=torch.float32, device=param.device)
 
 
+def alloc_grad_ex(param, shape=None):
+    """-> (buffer to ACCUMULATE the gradient of `param` into, what to hand autograd for it).  First producer of the pass: the
+    parameter's zeroed arena slice, returned to autograd; a later producer of the same pass (shared weights): the same slice,
+    accumulated in place, and `None` for autograd (dp.GradArena.retake); no arena: a fresh zero tensor."""
+    a = _grad_arena
+    if a is not None and param is not None:
+        v = a.take(param)
+        if v is not None:
+            v = v if shape is None else v.view(shape)
+            return v, v
+        v = a.retake(param)
+        if v is not None:
+            return (v if shape is None else v.view(shape)), None
+    z = torch.zeros(tuple(param.shape) if shape is None else shape, dtype=torch.float32, device=param.device)
+    return z, z
+
+
 def alloc_grad_block(params, shape):
     """one zero-initialised buffer covering the gradients of `params` back to back (fused q|k|v)"""
     a = _grad_arena
@@ -381,6 +398,26 @@ def gemm_trace_end():
         return []
     torch.cuda.synchronize()
     return [(name, fl, e0.elapsed_time(e1)) for name, fl, e0, e1 in tr]
+
+
+class trace_launch:
+    """`with trace_launch(flops):` around a direct library call that multiplies on the GEMM context of the current stream (the trunk's
+    implicit-GEMM convolutions): recorded like `gemm` when a trace is open, free otherwise"""
+
+    def __init__(self, flops):
+        self.flops = flops
+
+    def __enter__(self):
+        if _gemm_trace is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _gemm_trace is not None and exc[0] is None:
+            self.e1.record()
+            _gemm_trace.append((H.lib().fcmf_gemm_ctx_last_kernel(H.gemm_ctx()).decode(), float(self.flops), self.e0, self.e1))
+        return False
 
 
 # ---- deferred weight gradients -------------------------------------------------------------------------------------------
@@ -593,15 +630,16 @@ def _linear_bwd(x, w, dy, need_dx=True, need_dw=True, need_db=True, dx_epi=H.EPI
         dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
         gemm_dx(dy, master, w, dx, M, K, N, aux=dx_aux, epi=dx_epi)
     if need_dw:
-        dw = alloc_grad(master, (N, K)) if (master is not None and master.dtype == torch.float32 and master.is_contiguous()
-                                              and tuple(master.shape) == (N, K)) else \
-            torch.zeros((N, K), dtype=torch.float32, device=dy.device)
-        gemm(dy, x, dw, N, K, M, N, _ld(x), K, 1, 1, acc=True)
+        if master is not None and master.dtype == torch.float32 and master.is_contiguous() and tuple(master.shape) == (N, K):
+            dwbuf, dw = alloc_grad_ex(master, (N, K))         # (dw = None: accumulated in place into the slice an earlier use returned)
+        else:
+            dwbuf = dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+        gemm(dy, x, dwbuf, N, K, M, N, _ld(x), K, 1, 1, acc=True)
     if need_db:
         if bias_param is not None and bias_param.dtype == torch.float32 and tuple(bias_param.shape) == (N,):
             # straight into the parameter's (already zero) arena slice: no output tensor, no memset inside fcmf_colsum
-            db = alloc_grad(bias_param, (N,))
-            H.check(H.lib().fcmf_colsum(H.ptr(dy), H.ptr(db), M, N, N, H.dt(dy), 1, H.stream()), "fcmf_colsum")
+            dbbuf, db = alloc_grad_ex(bias_param, (N,))
+            H.check(H.lib().fcmf_colsum(H.ptr(dy), H.ptr(dbbuf), M, N, N, H.dt(dy), 1, H.stream()), "fcmf_colsum")
         else:
             db = colsum(dy, M, N, N)
     return dx, dw, db
@@ -880,10 +918,10 @@ class AddLNFn(torch.autograd.Function):
         dy2 = dy.reshape(rows, Hd).contiguous()
         dz = torch.empty_like(z)
         dx = torch.empty_like(z) if ctx.p > 0 else None
-        dg = alloc_grad(gamma, (Hd,))       # the arena slices (already zero) where an arena is active: no fill launches
-        db = alloc_grad(beta, (Hd,))
+        dgbuf, dg = alloc_grad_ex(gamma, (Hd,))       # the arena slices (already zero) where an arena is active: no fill launches
+        dbbuf, db = alloc_grad_ex(beta, (Hd,))          # (dg / db = None: a later use of shared parameters, accumulated in place)
         H.check(H.lib().fcmf_add_ln_bwd(H.ptr(dy2), H.ptr(z), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(dz),
-                                        H.ptr(dx), H.ptr(dg), H.ptr(db), 0, H.ptr(ln_workspace(rows, Hd, z.device)), rows, Hd, ctx.p, ctx.seed, H.dt(z),
+                                        H.ptr(dx), H.ptr(dgbuf), H.ptr(dbbuf), 0, H.ptr(ln_workspace(rows, Hd, z.device)), rows, Hd, ctx.p, ctx.seed, H.dt(z),
                                         H.stream()), "fcmf_add_ln_bwd")
         dxo = (dx if dx is not None else dz).view(ctx.xshape)
         dres = None if ctx.res_shape is None else dz.view(ctx.res_shape)

@@ -106,16 +106,19 @@ def conv2d_implicit(xp, conv, N, Ho, Wo, stats=False):
     assert Kpad == kh * kw * C
     y = torch.empty((N * Ho * Wo, Cout), dtype=xp.dtype, device=xp.device)
     blocks = _block_stats(N * Ho * Wo, Cout, Kpad, xp.dtype, xp.device) if stats else None
+    flops = 2.0 * N * Ho * Wo * Cout * Kpad
     if blocks is not None:
-        rc = H.lib().fcmf_conv_gemm_colstats(H.gemm_ctx(), H.ptr(xp), H.ptr(wm), H.ptr(y), H.ptr(blocks[0]), N, xp.shape[1], xp.shape[2],
-                                             C, Ho, Wo, kh, kw, conv.stride[0], Cout, H.stream())
+        with ops.trace_launch(flops):
+            rc = H.lib().fcmf_conv_gemm_colstats(H.gemm_ctx(), H.ptr(xp), H.ptr(wm), H.ptr(y), H.ptr(blocks[0]), N, xp.shape[1], xp.shape[2],
+                                                 C, Ho, Wo, kh, kw, conv.stride[0], Cout, H.stream())
         if rc == H.ERR_UNSUPPORTED:
             blocks = None
         else:
             H.check(rc, "fcmf_conv_gemm_colstats")
     if blocks is None:
-        H.check(H.lib().fcmf_conv_gemm(H.gemm_ctx(), H.ptr(xp), H.ptr(wm), H.ptr(y), N, xp.shape[1], xp.shape[2], C, Ho, Wo, kh, kw,
-                                       conv.stride[0], Cout, H.stream()), "fcmf_conv_gemm")
+        with ops.trace_launch(flops):
+            H.check(H.lib().fcmf_conv_gemm(H.gemm_ctx(), H.ptr(xp), H.ptr(wm), H.ptr(y), N, xp.shape[1], xp.shape[2], C, Ho, Wo, kh, kw,
+                                           conv.stride[0], Cout, H.stream()), "fcmf_conv_gemm")
     y = y.view(N, Ho, Wo, Cout)
     return (y, blocks) if stats else y
 
@@ -150,8 +153,9 @@ def conv2d_stem(v, conv, stats=False):
     wm = ops.shadows.derived(conv.weight, ("stem_runs", torch.bfloat16), build)
     y = torch.empty((N * Ho * Wo, Cout), dtype=torch.bfloat16, device=v.device)
     blocks = _block_stats(N * Ho * Wo, Cout, k * 32, torch.bfloat16, v.device) if stats else None
-    H.check(H.lib().fcmf_conv_gemm_runs(H.gemm_ctx(), H.ptr(buf), H.ptr(wm), H.ptr(y), H.ptr(blocks[0]) if blocks is not None else None, N, Hh + 2 * pad, Wp, 4, 32, Ho, Wo, k, 2,
-                                        Cout, H.stream()), "fcmf_conv_gemm_runs")
+    with ops.trace_launch(2.0 * N * Ho * Wo * Cout * k * 32):
+        H.check(H.lib().fcmf_conv_gemm_runs(H.gemm_ctx(), H.ptr(buf), H.ptr(wm), H.ptr(y), H.ptr(blocks[0]) if blocks is not None else None, N, Hh + 2 * pad, Wp, 4, 32, Ho, Wo, k, 2,
+                                            Cout, H.stream()), "fcmf_conv_gemm_runs")
     y = y.view(N, Ho, Wo, Cout)
     return (y, blocks) if stats else y
 
@@ -182,8 +186,9 @@ def conv2d_nhwc(x, conv, src_strides=None, stats=False):
     y = torch.empty((rows, Cout), dtype=dt, device=x.device)
     blocks = _block_stats(rows, Cout, Kpad, dt, x.device) if stats else None
     if blocks is not None:
-        rc = H.lib().fcmf_gemm_colstats(H.gemm_ctx(), H.ptr(A), H.ptr(wm), H.ptr(y), H.ptr(blocks[0]), rows, Cout, Kpad, Kpad, Kpad, Cout,
-                                        H.stream())
+        with ops.trace_launch(2.0 * rows * Cout * Kpad):
+            rc = H.lib().fcmf_gemm_colstats(H.gemm_ctx(), H.ptr(A), H.ptr(wm), H.ptr(y), H.ptr(blocks[0]), rows, Cout, Kpad, Kpad, Kpad, Cout,
+                                            H.stream())
         if rc == H.ERR_UNSUPPORTED:
             blocks = None
         else:
