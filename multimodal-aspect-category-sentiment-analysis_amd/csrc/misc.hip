@@ -502,10 +502,8 @@ __global__ __launch_bounds__(256) void embed_scale_bwd_kernel(const T* __restric
     return;
   }
   float* wr = dw + id * (int64_t)H;
-  for (int c = lane * 4; c < H; c += 256) {
-    const float4 d = Vec4<T>::load(dy + (int64_t)row * H + c);
-    atomicAdd(wr + c, d.x * scale); atomicAdd(wr + c + 1, d.y * scale); atomicAdd(wr + c + 2, d.z * scale); atomicAdd(wr + c + 3, d.w * scale);
-  }
+  for (int c = lane; c < H; c += 64)      // (256 contiguous bytes per atomic wave-instruction: see embed_bwd_kernel)
+    atomicAdd(wr + c, to_f32<T>(dy[(int64_t)row * H + c]) * scale);
 }
 // the decoder Attention pairs output slot s of batch element g with head (s * G + g) % heads (mm_modeling.py:79-85: inputs are
 // tiled head-major, weights batch-major).  The attention backward produces gradients per SLOT; the projections want them per

@@ -372,20 +372,14 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dz
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= ntok) return;
   const int64_t id = ids[row], ps = pos[row], ty = tt ? tt[row] : 0;
-  for (int c = lane * 4; c < H; c += 256) {
-    const float4 d = Vec4<T>::load(dz + (int64_t)row * H + c);
-    if (id != pad_id) {
-      float* w = dword + id * H + c;
-      atomicAdd(w + 0, d.x); atomicAdd(w + 1, d.y); atomicAdd(w + 2, d.z); atomicAdd(w + 3, d.w);
-    }
-    if (dpos && ps != pad_id) {
-      float* q = dpos + ps * H + c;
-      atomicAdd(q + 0, d.x); atomicAdd(q + 1, d.y); atomicAdd(q + 2, d.z); atomicAdd(q + 3, d.w);
-    }
-    if (dtt && ty != 0) {  // type row 0 is summed by a column reduction (every token hits it)
-      float* q = dtt + ty * H + c;
-      atomicAdd(q + 0, d.x); atomicAdd(q + 1, d.y); atomicAdd(q + 2, d.z); atomicAdd(q + 3, d.w);
-    }
+  // one column per lane and trip: every atomic wave-instruction covers 256 CONTIGUOUS bytes of the destination row -- the shape the
+  // memory-side float atomics run at full rate for (MI355X_MICROARCH.md, Global float atomics).  Four consecutive columns per lane
+  // (round 3) spread each instruction over a 1-KiB span: 327 us for the 49152 x 768 word-table gradient against ~120 us of atomic bandwidth.
+  for (int c = lane; c < H; c += 64) {
+    const float d = to_f32<T>(dz[(int64_t)row * H + c]);
+    if (id != pad_id) atomicAdd(dword + id * H + c, d);
+    if (dpos && ps != pad_id) atomicAdd(dpos + ps * H + c, d);
+    if (dtt && ty != 0) atomicAdd(dtt + ty * H + c, d);  // type row 0 is summed by a column reduction (every token hits it)
   }
 }
 

@@ -989,6 +989,8 @@ class EmbedLNFn(torch.autograd.Function):
         ctx.save_for_backward(ids, pos, tt, z, gamma, mean, rstd)
         ctx.p, ctx.seed, ctx.pad_id = p, seed, pad_id
         ctx.word = word if (word.dtype == torch.float32 and word.is_contiguous()) else None   # (the Parameter: arena lookup)
+        ok = lambda t: t if (t is not None and t.dtype == torch.float32 and t.is_contiguous()) else None
+        ctx.tabs = (ok(ptab), ok(ttab), ok(gamma), ok(beta))                                     # (likewise: their arena slices)
         ctx.shapes = (word.shape, ptab.shape, ttab.shape)
         return y.view(*ids.shape, Hd)
 
@@ -1003,14 +1005,16 @@ class EmbedLNFn(torch.autograd.Function):
             H.check(L.fcmf_dropout(H.ptr(d), H.ptr(o), d.numel(), ctx.p, ctx.seed, H.dt(d), H.stream()), "fcmf_dropout")
             d = o
         dz = torch.empty_like(z)
-        dg = torch.zeros(Hd, dtype=torch.float32, device=z.device)
-        db = torch.zeros(Hd, dtype=torch.float32, device=z.device)
+        ptab, ttab, gpar, bpar = ctx.tabs
+        zeros = lambda shape: torch.zeros(shape, dtype=torch.float32, device=z.device)
+        dg = alloc_grad(gpar, (Hd,)) if gpar is not None else zeros(Hd)        # (arena slices: already zero, no fill launches)
+        db = alloc_grad(bpar, (Hd,)) if bpar is not None else zeros(Hd)
         H.check(L.fcmf_add_ln_bwd(H.ptr(d), H.ptr(z), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(dz), 0, H.ptr(dg),
                                   H.ptr(db), 0, H.ptr(ln_workspace(ntok, Hd, z.device)), ntok, Hd, 0.0, 0, H.dt(z), H.stream()), "fcmf_add_ln_bwd")
         ws, ps, ts = ctx.shapes
         dword = alloc_grad(ctx.word, ws) if ctx.word is not None else torch.zeros(ws, dtype=torch.float32, device=z.device)
-        dpos = torch.zeros(ps, dtype=torch.float32, device=z.device)
-        dtt = torch.zeros(ts, dtype=torch.float32, device=z.device)
+        dpos = alloc_grad(ptab, ps) if ptab is not None else zeros(ps)
+        dtt = alloc_grad(ttab, ts) if ttab is not None else zeros(ts)
         two_d = ids.dim() == 2 and pos.is_contiguous()
         H.check(L.fcmf_embed_bwd(H.ptr(dz), H.ptr(ids), H.ptr(pos), H.ptr(tt), H.ptr(dword), None if two_d else H.ptr(dpos),
                                  H.ptr(dtt), ntok, Hd, ctx.pad_id, H.dt(dz), H.stream()), "fcmf_embed_bwd")
