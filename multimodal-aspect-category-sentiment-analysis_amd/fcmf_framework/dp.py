@@ -293,7 +293,9 @@ class GradReducer:
                 end += 1
                 if size >= self.group_elems and not flush:
                     break
-            if end == self._next or not (flush or size >= self.group_elems or end == nb):
+            # (everything but the LAST bucket complete: nothing is left to batch with -- FCMF's last bucket is the 196 MB word-embedding
+            #  gradient, produced by the final backward kernel; the layers in front of it must not wait for it)
+            if end == self._next or not (flush or size >= self.group_elems or end >= nb - 1):
                 return
             self._flush_range(self._next, end)
             self.group_log.append((self._next, end - 1, sum(len(self.buckets[b][2]) - len(self._ready[b]) for b in range(self._next, end))))
