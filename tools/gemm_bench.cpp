@@ -55,6 +55,13 @@ int main(int argc, char** argv) {
       {"sq   NT 8192^3", 8192, 8192, 8192, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"sq   TN 8192^3 bf16 out", 8192, 8192, 8192, 1, 1, FCMF_EPI_NONE, 0, 0},
 
+      {"iaog NT 8192x768x768", 8192, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"iaog NT 8192x2304x768", 8192, 2304, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"iaog NT 8192x3072x768 gelu", 8192, 3072, 768, 0, 0, FCMF_EPI_GELU, 0, 0},
+      {"iaog NT 8192x768x3072", 8192, 768, 3072, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"iaog NT 8192x768x2304 add", 8192, 768, 2304, 0, 0, FCMF_EPI_ADD, 0, 0},
+      {"iaog NT 768x768x768", 768, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
+      {"iaog NT 768x1536x768", 768, 1536, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"small NT 2048x768x768", 2048, 768, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"small NT 2048x3072x768", 2048, 3072, 768, 0, 0, FCMF_EPI_NONE, 0, 0},
       {"small NT 2048x768x3072", 2048, 768, 3072, 0, 0, FCMF_EPI_NONE, 0, 0},
