@@ -403,8 +403,9 @@ def run_resnet(args, rank, world, dev):
         "metric": "ResNet-152 trunk crops/sec (forward, train-mode grouped BatchNorm)", "value": round(world * crops * args.steps / dt, 1),
         "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic crops, random-init weights",
-        "config": {"workload": f"ResNet-152 trunk forward of one image pass: {NI} call groups x {B} crops of 224x224, NHWC GEMM "
-                               "convolutions (patch matrix for 7x7 / 3x3 / strided), per-group batch statistics, -> [B*NI, 49, 2048]",
+        "config": {"workload": f"ResNet-152 trunk forward of one image pass: {NI} call groups x {B} crops of 224x224, NHWC implicit-GEMM "
+                               "convolutions (3x3, strided 1x1, the 7x7 stem over RGB0 runs), per-group batch statistics out of the "
+                               "convolution epilogues, -> [B*NI, 49, 2048]",
                    "crops_per_step": crops, "parallelism": f"dp{world}"},
         "achieved_tflops_conv": round(crops * gflop_per_crop / ms, 1), "finite": bool(torch.isfinite(y).all().item()),
         "roofline": gemm_roofline(trace),

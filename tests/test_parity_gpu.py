@@ -669,14 +669,23 @@ def test_fcmf_large_geometry_bf16_and_fp32(dev):
         names = [n for n, _, _ in ops.gemm_trace_end()]
         nf8 = sum(n.startswith("gemm_fp8") for n in names)
         assert nf8 >= 24 * 8 - 8, (nf8, len(names))            # 24 layers x (qkv, out, ffn1, ffn2) x (forward, dX), first-layer dX aside
+        loss8 = model.loss_aspects(l8, b["labels"]).item()
+        loss16 = model.loss_aspects(l16, b["labels"]).item()
         e8 = max_err(l8[:, 0], ref)
         assert e8 < 0.5 * ref.abs().max().item(), (e8, ref.abs().max().item())
+        # the STEP quantities against the bf16 step of the same weights and batch (round-3 advisor finding: pinned by no fixture):
+        # loss within 2 % (measured 0.74 %: 2.6422 vs 2.6227), model-wide gradient norm within 15 % (measured 2.1 %: 122.8 vs 120.3)
+        assert abs(loss8 - loss16) < 2e-2 * abs(loss16), (loss8, loss16)
         g8 = _named_grads(model)
+        n8 = sum(g8[n].double().pow(2).sum().item() for n in g16 if not n.endswith(ZERO_GRAD)) ** 0.5
+        n16 = sum(g16[n].double().pow(2).sum().item() for n in g16 if not n.endswith(ZERO_GRAD)) ** 0.5
+        assert abs(n8 - n16) < 0.15 * n16, (n8, n16)
         keys = [n for n in g16 if not n.endswith(ZERO_GRAD) and g16[n].norm().item() > 0]
         a = torch.cat([(g8[n] / (g16[n].norm() + 1e-30)).flatten() for n in keys])
         r = torch.cat([(g16[n] / (g16[n].norm() + 1e-30)).flatten() for n in keys])
         assert all(torch.isfinite(g8[n]).all() for n in keys)
         assert _cos(a, r) > 0.9, _cos(a, r)
+        print(f"fcmf-large fp8 step vs bf16 step: loss {loss8:.5f} vs {loss16:.5f}, gradient norm {n8:.4e} vs {n16:.4e}")
         print(f"fcmf-large fp8: logits err vs fp32 oracle {e8:.3e} (|ref|max {ref.abs().max().item():.3f}; bf16: {max_err(l16[:, 0], ref):.3e}), "
               f"{nf8} e4m3 GEMMs of {len(names)}, gradient cosine vs the bf16 graph {_cos(a, r):.5f}")
     finally:
