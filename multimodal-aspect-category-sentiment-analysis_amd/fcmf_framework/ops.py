@@ -1210,8 +1210,8 @@ class BoxBiasFn(torch.autograd.Function):
         c, ww, wb = ctx.saved_tensors
         G, N, _ = c.shape
         heads = ww.shape[0]
-        dw = torch.zeros_like(ww)
-        db = torch.zeros_like(wb)
+        buf = torch.zeros(ww.numel() + wb.numel(), dtype=torch.float32, device=ww.device)       # (one fill for both)
+        dw, db = buf[:ww.numel()].view_as(ww), buf[ww.numel():].view_as(wb)
         d = dbias.contiguous().float()
         H.check(H.lib().fcmf_box_bias_bwd(H.ptr(c), H.dt(c), H.ptr(box_dim_mat(c.device)), H.ptr(ww), H.ptr(wb), H.ptr(d),
                                           H.ptr(dw), H.ptr(db), G, N, heads, H.stream()), "fcmf_box_bias_bwd")

@@ -192,9 +192,14 @@ class FusedAdamW(Optimizer):
                                   if len(self.state[p]) else None for p, _ in plist]):
             self._build(plist, device)
             T = self._tables
-        g_ptrs = torch.tensor([p.grad.data_ptr() for p, _ in plist], dtype=torch.int64).to(device, non_blocking=True)
+        # gradient / shadow addresses: with the gradient arena they are the same every step -- uploaded again only when they change
         sh = [ops.shadows.peek(p) for p, _ in plist]
-        sh_ptrs = torch.tensor([0 if s is None else s.data_ptr() for s in sh], dtype=torch.int64).to(device, non_blocking=True)
+        gl, sl = [p.grad.data_ptr() for p, _ in plist], [0 if s is None else s.data_ptr() for s in sh]
+        if T.get('gl') != gl:
+            T['gl'], T['g_ptrs'] = gl, torch.tensor(gl, dtype=torch.int64).to(device, non_blocking=True)
+        if T.get('sl') != sl:
+            T['sl'], T['sh_ptrs'] = sl, torch.tensor(sl, dtype=torch.int64).to(device, non_blocking=True)
+        g_ptrs, sh_ptrs = T['g_ptrs'], T['sh_ptrs']
         L = H.lib()
         st = H.stream()
         if self._sumsq is None or self._sumsq.device != device:
