@@ -355,7 +355,7 @@ static int grid_for(int64_t n, int per) {
 
 // 2: fcmf_attn_mfma_bwd gained `colsum`; 3: explicit GEMM context (fcmf_gemm takes a ctx), fcmf_dp_*; 4: fcmf_embed_scale_* take the table's row count
 extern "C" int fcmf_abi_version(void) { return 4; }
-extern "C" const char* fcmf_build_info(void) { return "libfcmf_hip gfx950 (CDNA4, wave64) abi 3"; }
+extern "C" const char* fcmf_build_info(void) { return "libfcmf_hip gfx950 (CDNA4, wave64) abi 4"; }
 
 extern "C" int fcmf_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, float* loss_rows, float* nvalid, int n,
                              int C, int64_t ignore_index, int dtype, void* stream) {

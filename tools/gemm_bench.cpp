@@ -106,7 +106,7 @@ int main(int argc, char** argv) {
     if (only && strncmp(sh.name, only, strlen(only)) != 0) continue;
     int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.N : sh.K, ldc = sh.N;
     auto run = [&]() {
-      return fcmf_gemm(ctx, A, B, C, sh.acc ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU || sh.epi == FCMF_EPI_ADD) ? AUX : nullptr, nullptr,
+      return fcmf_gemm(ctx, A, B, C, (sh.acc || getenv("FCMF_BENCH_NO_BIAS")) ? nullptr : bias, (sh.epi == FCMF_EPI_GELU || sh.epi == FCMF_EPI_DGELU || sh.epi == FCMF_EPI_ADD) ? AUX : nullptr, nullptr,
                        sh.M, sh.N, sh.K, lda, ldb, ldc, sh.ta, sh.tb, FCMF_BF16, sh.out_f32 ? FCMF_F32 : FCMF_BF16, sh.epi, sh.acc, nullptr);
     };
     int rc = run(); rc |= run();
