@@ -376,6 +376,17 @@ int fcmf_bn_finalize_apply(const void* x, const void* res, void* y, const double
  * bf16, C a power of two >= 64, w [Cout, kh*kw*C] row-major in (ky, kx, c) order, y [n*Ho*Wo, Cout]. */
 int fcmf_conv_gemm(fcmf_gemm_ctx* ctx, const void* x, const void* w, void* y, int n, int Hp, int Wp, int C, int Ho, int Wo,
                    int kh, int kw, int stride, int Cout, void* stream);
+/* f32 C (+)= op(A) op(B) of bf16 operands with a COLUMN-BLOCKED output: element (i, j) is stored at
+ *   C + (j / col_block) * col_block_stride + i * ldc + j % col_block          (col_block % 4 == 0, N % col_block == 0).
+ * The per-head projection weights of the IAOG decoder's Attention are [n_head, E, d] tensors (mm_modeling.py:57-58); their gradient
+ * dW^T [E, n_head * d] = x^T dY written with col_block = d, col_block_stride = E * d, ldc = d lands in exactly that layout (the
+ * autograd of the reference's repeat + bmm, mm_modeling.py:79-92, without a permute copy per parameter).  Split-K through the
+ * context's workspace only (the reduce pass writes the blocked layout): FCMF_ERR_UNSUPPORTED otherwise -- callers fall back to
+ * fcmf_gemm into a plain buffer. */
+int fcmf_gemm_colblocks(fcmf_gemm_ctx* ctx, const void* A, const void* B, float* C, int M, int N, int K, int64_t lda,
+                        int64_t ldb, int64_t ldc, int trans_a, int trans_b, int col_block, int64_t col_block_stride,
+                        int accumulate, void* stream);
+
 /* `count` same-shape weight gradients in one launch: C_i [M, N] float32 (+)= A_i^T B_i with A_i = dY_i [K, M], B_i = X_i [K, N]
  * (bf16, K = tokens) -- nn.Linear's weight gradient (loss.backward(), run_multimodal_fcmf.py:466) for the layers of an encoder,
  * which the host queues during the backward pass and multiplies together: the tiles of all matrices form ONE work list for the

@@ -1563,8 +1563,12 @@ static int launch_bf16_tile(const GemmParams& p, int out_dtype, dim3 grid, hipSt
 // C (+)= sum_z ws[z]: the reduce pass of the workspace split-K (partials were just written: L2 / Infinity Cache hits)
 // C (+)= sum_z ws[z] for partial tiles stored in the FRAGMENT layout (the f32 epilogue above): ws[z][tile][wave][fj][fi][lane][4].
 // One thread sums the `ksplit` copies of one 16-byte piece (coalesced KiB reads per wave) and writes it to its (row, column).
+// cblk > 0: COLUMN-BLOCKED output -- column j of row i lives at C + (j / cblk) * cblk_stride + i * ldc + j % cblk: the per-head weight
+// gradients of the IAOG decoder's Attention, dW^T [E, heads * d] = x^T dY, land directly in the parameters' [heads, E, d] layout
+// (cblk = d, cblk_stride = E * d, ldc = d) instead of a [heads * d, E] buffer that autograd has to permute-copy per parameter.
 __global__ __launch_bounds__(256) void splitk_reduce_frag_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
-                                                                 int64_t ldc, int ksplit, int tiles, int tiles_n, int accumulate) {
+                                                                 int64_t ldc, int ksplit, int tiles, int tiles_n, int accumulate,
+                                                                 int cblk, int64_t cblk_stride) {
   const int64_t total = (int64_t)tiles * (GB * GB / 4);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int tile = (int)(i >> 14), r = (int)(i & 16383);          // 16384 pieces of 4 floats per 256 x 256 tile
@@ -1573,7 +1577,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_frag_kernel(const float* __
     const int row = (tile / tiles_n) * GB + wm * 128 + fi * 16 + (lane & 15);
     const int col = (tile % tiles_n) * GB + wn * 64 + fj * 16 + (lane >> 4) * 4;
     if (row >= M || col >= N) continue;
-    float* c = C + (int64_t)row * ldc + col;
+    float* c = cblk ? C + (int64_t)(col / cblk) * cblk_stride + (int64_t)row * ldc + (col % cblk) : C + (int64_t)row * ldc + col;
     f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int z = 0; z < ksplit; ++z) s += *reinterpret_cast<const f32x4*>(ws + ((int64_t)z * tiles + tile) * (GB * GB) + (int64_t)r * 4);
@@ -1678,7 +1682,8 @@ extern "C" int fcmf_gemm_colstats_block_rows(const fcmf_gemm_ctx* ctx, int M, in
 
 static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, const float* bias, void* aux, float* colsum,
                      int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int in_dtype,
-                     int out_dtype, int epilogue, int accumulate, void* stream, const ConvGeom* cv, float* colstats = nullptr) {
+                     int out_dtype, int epilogue, int accumulate, void* stream, const ConvGeom* cv, float* colstats = nullptr,
+                     int cblk = 0, int64_t cblk_stride = 0) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0) return FCMF_ERR_ARG;
   const fcmf_gemm_ctx& cfg = ctx ? *ctx : g_default_ctx;
   char name_sink[96];
@@ -1726,6 +1731,10 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
                  ((int64_t)M * N >= (int64_t)256 * 256 * 64 || (splittable && K >= 512));
     if (cfg.force_tile == 128) large = false;
     if (cfg.force_tile == 256 || cfg.force_tile == 192) large = tile_ok;
+    if (cblk) {      // column-blocked output: written by the fragment-layout reduce pass only (f32, split K through the workspace)
+      if (!(tile_ok && splittable && out_dtype == FCMF_F32 && cfg.ws && M >= 256 && N >= 256 && cblk % 4 == 0 && N % cblk == 0)) return FCMF_ERR_UNSUPPORTED;
+      large = true;
+    }
     // narrow outputs with many rows (the trunk's 64- / 128-channel convolutions): the persistent kernel's 4 x 2 / 8 x 1 wave layouts
     const bool narrow = cfg.force_tile == 0 && cfg.kb64 && tile_ok && !colsum && !aux && !accumulate && !trans_a && !trans_b &&
                         out_dtype == FCMF_BF16 && epilogue == FCMF_EPI_NONE && narrow_shape(M, N, K);
@@ -1796,6 +1805,7 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
       if (p.ksplit > 1 && !accumulate && !p.ws) {       // (no workspace of that size: float atomics would need a zeroed C)
         p.ksplit = 1; p.ktiles_per_split = nk; p.total_items = tiles_l;
       }
+      if (cblk && !(p.ksplit > 1 && p.ws && frag_ws)) return FCMF_ERR_UNSUPPORTED;   // (only the reduce pass knows the blocked layout)
       {
         static const char* const epi_names[] = {"NONE", "GELU", "TANH", "DGELU", "DTANH", "ADD"};
         if (kb == 64) snprintf(last_kernel, NAME, "gemm_bf16_tile%dk64_kernel<%s>", tm, epi_names[epilogue]);
@@ -1812,7 +1822,7 @@ static int gemm_impl(fcmf_gemm_ctx* ctx, const void* A, const void* B, void* C, 
           const int64_t total4 = (int64_t)tiles_l * (GB * GB / 4);
           const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
           hipLaunchKernelGGL(splitk_reduce_frag_kernel, dim3(blocks), dim3(256), 0, st, p.ws, reinterpret_cast<float*>(C), M, N, ldc,
-                             p.ksplit, tiles_l, (N + GB - 1) / GB, accumulate);
+                             p.ksplit, tiles_l, (N + GB - 1) / GB, accumulate, cblk, cblk_stride);
         } else {
           const int64_t total4 = (int64_t)M * N / 4;
           const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
@@ -2018,6 +2028,14 @@ extern "C" int fcmf_gemm(fcmf_gemm_ctx* ctx, const void* A, const void* B, void*
                          int out_dtype, int epilogue, int accumulate, void* stream) {
   return gemm_impl(ctx, A, B, C, bias, aux, colsum, M, N, K, lda, ldb, ldc, trans_a, trans_b, in_dtype, out_dtype, epilogue,
                    accumulate, stream, nullptr);
+}
+
+extern "C" int fcmf_gemm_colblocks(fcmf_gemm_ctx* ctx, const void* A, const void* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                                   int64_t ldc, int trans_a, int trans_b, int col_block, int64_t col_block_stride, int accumulate,
+                                   void* stream) {
+  if (col_block <= 0 || col_block_stride <= 0 || ldc < col_block) return FCMF_ERR_ARG;
+  return gemm_impl(ctx, A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, trans_a, trans_b, FCMF_BF16, FCMF_F32, FCMF_EPI_NONE,
+                   accumulate, stream, nullptr, nullptr, col_block, col_block_stride);
 }
 
 // ---- batched weight gradients -----------------------------------------------------------------------------------------

@@ -42,6 +42,7 @@ SIGNATURES = {
     "fcmf_gemm_ctx_set_workspace": [_vp, _vp, _i64],
     "fcmf_gemm_ctx_tune": [_vp, _i, _i, _i, _i64],
     "fcmf_gemm_ctx_last_kernel": [_vp],
+    "fcmf_gemm_colblocks": [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i64, _i, _vp],
     "fcmf_quant_fp8_rows": [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp],
     "fcmf_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _vp],
     "fcmf_colsum": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],

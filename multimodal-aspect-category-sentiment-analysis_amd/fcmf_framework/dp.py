@@ -23,9 +23,11 @@ ALIGN = 64      # elements: every slice starts on a 256-byte boundary (16-byte v
 
 
 class GradArena:
-    def __init__(self, params, blocks=()):
+    def __init__(self, params, blocks=(), pad_rows=32):
         """params: the parameters that receive gradients, in registration order.  blocks: lists of parameters that
-        must sit next to each other, in the given order (fused q|k|v weight / bias gradients)."""
+        must sit next to each other, in the given order (fused q|k|v weight / bias gradients).  pad_rows: a large 2-D parameter
+        whose row count is no multiple of this (the 64001-row tied vocabulary matrix) gets zeroed SLACK rows behind its slice, so
+        that the MFMA weight-gradient GEMM -- which writes whole 32-row groups -- can accumulate straight into it (`take_rows`)."""
         params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in params:                      # tied parameters (decoder.dense.weight) appear once
@@ -45,6 +47,7 @@ class GradArena:
                     order.append(q)
         self.order = order
         self.offset, off = {}, 0
+        self.slack = {}                       # parameter -> zeroed elements behind its slice (see pad_rows)
         self.packed = set()                   # parameters packed tight behind their block head (no alignment gap before them)
         for p in order:
             adj = id(p) in in_block and blocks[in_block[id(p)]][0] is not p      # packed tight behind its block head
@@ -54,6 +57,9 @@ class GradArena:
                 self.packed.add(id(p))
             self.offset[id(p)] = off
             off += p.numel()
+            if pad_rows and p.dim() == 2 and p.shape[0] >= 8192 and p.shape[0] % pad_rows:
+                self.slack[id(p)] = (pad_rows - p.shape[0] % pad_rows) * p.shape[1]
+                off += self.slack[id(p)]
         self.total = (off + ALIGN - 1) // ALIGN * ALIGN
         dev = self.params[0].device
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
@@ -76,6 +82,14 @@ class GradArena:
             if isinstance(m, QKVStorageMixin):
                 blocks.append([m.query.weight, m.key.weight, m.value.weight])
                 blocks.append([m.query.bias, m.key.bias, m.value.bias])
+        # IAOG decoder: the per-head projection weights whose gradients ONE column-blocked GEMM writes (ops.head_weight_grad) --
+        # [w_kx | w_qx] of every self attention, and the w_kx of ALL blocks' cross attention (their keys are hoisted into one GEMM)
+        for m in model.modules():
+            blks = getattr(m, "blks", None)
+            if blks is not None and all(hasattr(b, "attention1") and hasattr(b, "attention2") for b in blks):
+                for b in blks:
+                    blocks.append([b.attention1.w_kx, b.attention1.w_qx])
+                blocks.append([b.attention2.w_kx for b in blks])
         return cls(list(extra) + [p for n, p in model.named_parameters() if not skip(n)], blocks)
 
     # ---- step protocol -------------------------------------------------------------------------
@@ -133,6 +147,23 @@ class GradArena:
             return None
         return self.view[id(p)]
 
+    def take_rows(self, param, rows):
+        """(buffer [rows, cols] starting at the slice of the 2-D `param` and running into its slack, what to hand autograd) for a
+        producer that writes `rows` >= param.shape[0] rows (the padded vocabulary projection); None if the slack does not cover it.
+        First producer of the pass: autograd gets the slice; a later one: None (accumulated in place, see retake)."""
+        p = self._by_ptr.get(param.data_ptr())
+        if p is None or p.dim() != 2 or p.numel() != param.numel() or p.grad is not None:
+            return None
+        cols = p.shape[1]
+        if (rows - p.shape[0]) * cols > self.slack.get(id(p), 0) or rows < p.shape[0]:
+            return None
+        off = self.offset[id(p)]
+        buf = self.flat[off:off + rows * cols].view(rows, cols)
+        if id(p) in self._taken:
+            return buf, None
+        self._taken.add(id(p))
+        return buf, self.view[id(p)].view_as(p)      # (a fresh alias: autograd adopts only a tensor object it alone holds)
+
     def retake_block(self, params):
         ps = [self._by_ptr.get(q.data_ptr()) for q in params]
         if any(p is None or id(p) not in self._taken or p.grad is not None for p in ps):
@@ -142,6 +173,13 @@ class GradArena:
             if self.offset[id(b)] != self.offset[id(a)] + a.numel():
                 return None
         return self.flat[off:off + sum(p.numel() for p in ps)]
+
+    def untake(self, params):
+        """give back slices claimed by take / take_block that nothing was written to (a kernel refused the shape)"""
+        for q in params:
+            p = self._by_ptr.get(q.data_ptr())
+            if p is not None:
+                self._taken.discard(id(p))
 
     def take_block(self, params):
         """one tensor covering the adjacent slices of `params` (or None)"""

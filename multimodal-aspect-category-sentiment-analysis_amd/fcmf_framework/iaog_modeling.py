@@ -120,6 +120,9 @@ class _SelfQuirkAttentionFn(torch.autograd.Function):
         else:
             _, kn = _pair_layouts(wk, wq, x2.dtype)
             ops.gemm(dkq, kn(), dx, G * T, E, 2 * HD, 2 * HD, 2 * HD, E, 0, 0)               # NT: both operands K-contiguous
+        direct = ops.head_weight_grad(x2, dkq, [wk, wq])          # straight into the two parameters' adjacent [n_head, E, d] arena slices
+        if direct is not None:
+            return dx.view(xshape), direct[0], direct[1], None, None
         dwl = torch.empty((2 * HD, E), dtype=torch.float32, device=x2.device)
         ops.gemm(dkq, x2, dwl, 2 * HD, E, G * T, 2 * HD, ops._ld(x2), E, 1, 1)                # [2*n_head*d, E] = dkq^T x
         dw = dwl.view(2, nh, d, E).permute(0, 1, 3, 2)                                        # -> the parameters' [n_head, E, d]
@@ -172,6 +175,9 @@ class _HoistedKeysFn(torch.autograd.Function):
         else:
             wt = ops.shadows.derived(wks[0], ("hoist_kn", e2.dtype, nb, wks[-1].data_ptr()), kn)
             ops.gemm(dk, wt, de, G * T, E, nb * HD, nb * HD, nb * HD, E, 0, 0)
+        direct = ops.head_weight_grad(e2, dk, list(wks))          # every block's w_kx: adjacent arena slices (dp.GradArena.for_model)
+        if direct is not None:
+            return (de.view(eshape),) + tuple(direct)
         dwl = torch.empty((nb * HD, E), dtype=torch.float32, device=e2.device)
         ops.gemm(dk, e2, dwl, nb * HD, E, G * T, nb * HD, ops._ld(e2), E, 1, 1)
         dw = dwl.view(nb, nh, d, E).permute(0, 1, 3, 2)

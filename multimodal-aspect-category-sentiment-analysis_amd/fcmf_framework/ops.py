@@ -528,6 +528,45 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI
         _gemm_trace.append((H.lib().fcmf_gemm_ctx_last_kernel(ctx).decode(), 2.0 * M * N * K, e0, e1))
 
 
+HEAD_WGRAD_DIRECT = os.environ.get("FCMF_HEAD_WGRAD_DIRECT", "1") == "1"      # (A/B switch)
+
+
+def head_weight_grad(x2, dy2, params):
+    """gradient of the per-head projection weights `params` (float32 Parameters [n_head, E, d], side by side in dy2's columns) of the
+    IAOG decoder's Attention, written DIRECTLY in the parameters' layout into their adjacent arena slices: dW^T [E, len * n_head * d]
+    = x2^T dy2 through fcmf_gemm_colblocks (column block = d, block stride = E * d, row stride = d).  -> the tensors to hand autograd
+    (the arena views), or None when it does not apply (no arena, slices not adjacent / already claimed, shape the blocked path
+    refuses): the caller then multiplies into a plain [n * d, E] buffer and lets autograd permute-copy it (round 3: 96 launches
+    per IAOG step)."""
+    a = _grad_arena
+    if a is None or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16 or not HEAD_WGRAD_DIRECT:
+        return None
+    nh, E, d = params[0].shape
+    if any(p.dtype != torch.float32 or tuple(p.shape) != (nh, E, d) for p in params) or d % 4:
+        return None
+    M, N = x2.shape[0], len(params) * nh * d
+    if E < 256 or N < 256 or dy2.shape[1] != N or not dy2.is_contiguous():
+        return None
+    flat = a.take_block(list(params)) if len(params) > 1 else a.take(params[0])
+    if flat is None:
+        return None
+    ctx = H.gemm_ctx(workspace=True)
+    if _gemm_trace is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = H.lib().fcmf_gemm_colblocks(ctx, H.ptr(x2), H.ptr(dy2), H.ptr(flat), E, N, M, _ld(x2), N, d, 1, 1, d, E * d, 0, H.stream())
+    if rc == H.ERR_UNSUPPORTED:
+        a.untake(params)
+        return None
+    H.check(rc, "fcmf_gemm_colblocks")
+    if _gemm_trace is not None:
+        e1.record()
+        _gemm_trace.append((H.lib().fcmf_gemm_ctx_last_kernel(ctx).decode(), 2.0 * E * N * M, e0, e1))
+    # (FRESH aliases: autograd adopts a gradient as p.grad without a copy only when it is the sole holder of the tensor object --
+    #  the arena's own view objects would be cloned)
+    return [a.view[id(a._by_ptr[p.data_ptr()])].view(nh, E, d) for p in params]
+
+
 def quant_fp8_rows(x, rows, K, ldx, out=None):
     """x [rows, K] (bf16 / f32 rows at stride ldx) -> (q [rows, K] uint8 e4m3, scale [rows] float32) through fcmf_quant_fp8_rows"""
     H.require_cuda(x)
@@ -722,9 +761,13 @@ class HeadLinearFn(torch.autograd.Function):
                 gemm(dy2, kn(), dx, M, E, N, N, N, E, 0, 0)                  # NT: both operands K-contiguous
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dwl = torch.empty((N, E), dtype=torch.float32, device=dy2.device)    # (fresh buffer: written, not accumulated into)
-            gemm(dy2, x2, dwl, N, E, M, N, _ld(x2), E, 1, 1)                 # [n_head*d, E] = dy^T x
-            dw = dwl.view(nh, d, E).permute(0, 2, 1)                         # the parameter's [n_head, E, d] layout
+            direct = head_weight_grad(x2, dy2, [w])                          # straight into the parameter's [n_head, E, d] arena slice
+            if direct is not None:
+                dw = direct[0]
+            else:
+                dwl = torch.empty((N, E), dtype=torch.float32, device=dy2.device)    # (fresh buffer: written, not accumulated into)
+                gemm(dy2, x2, dwl, N, E, M, N, _ld(x2), E, 1, 1)                 # [n_head*d, E] = dy^T x
+                dw = dwl.view(nh, d, E).permute(0, 2, 1)                         # the parameter's [n_head, E, d] layout
         return dx, dw
 
 
@@ -835,9 +878,16 @@ class VocabCrossEntropyFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = gemm_dx_long_k(d, w, M, K, Vp, K).view(xshape)
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros((Vp, K), dtype=torch.float32, device=x2.device)
+            # the tied vocabulary matrix: its arena slice has zeroed slack rows up to Vp (dp.GradArena pad_rows), so the padded product
+            # accumulates straight into it -- no 196 MB zero fill, and the embedding lookup's gradient (the other producer of the tied
+            # matrix) adds to the same memory in place instead of through a 196 MB autograd add
+            got = _grad_arena.take_rows(weight, Vp) if (_grad_arena is not None and weight.dtype == torch.float32 and weight.is_contiguous()) else None
+            if got is not None:
+                dwp, dw = got
+            else:
+                dwp = torch.zeros((Vp, K), dtype=torch.float32, device=x2.device)
+                dw = dwp[:V]
             gemm(d, x2, dwp, Vp, K, M, Vp, _ld(x2), K, 1, 1, acc=True)
-            dw = dwp[:V]
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum(d, M, Vp, Vp)[:V]
         return dx, dw, db, None, None
@@ -1012,11 +1062,14 @@ class EmbedLNFn(torch.autograd.Function):
         H.check(L.fcmf_add_ln_bwd(H.ptr(d), H.ptr(z), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), H.ptr(dz), 0, H.ptr(dg),
                                   H.ptr(db), 0, H.ptr(ln_workspace(ntok, Hd, z.device)), ntok, Hd, 0.0, 0, H.dt(z), H.stream()), "fcmf_add_ln_bwd")
         ws, ps, ts = ctx.shapes
-        dword = alloc_grad(ctx.word, ws) if ctx.word is not None else torch.zeros(ws, dtype=torch.float32, device=z.device)
+        if ctx.word is not None:
+            dwordbuf, dword = alloc_grad_ex(ctx.word, ws)      # (dword = None: the tied matrix's slice was claimed by the vocabulary projection)
+        else:
+            dwordbuf = dword = torch.zeros(ws, dtype=torch.float32, device=z.device)
         dpos = alloc_grad(ptab, ps) if ptab is not None else zeros(ps)
         dtt = alloc_grad(ttab, ts) if ttab is not None else zeros(ts)
         two_d = ids.dim() == 2 and pos.is_contiguous()
-        H.check(L.fcmf_embed_bwd(H.ptr(dz), H.ptr(ids), H.ptr(pos), H.ptr(tt), H.ptr(dword), None if two_d else H.ptr(dpos),
+        H.check(L.fcmf_embed_bwd(H.ptr(dz), H.ptr(ids), H.ptr(pos), H.ptr(tt), H.ptr(dwordbuf), None if two_d else H.ptr(dpos),
                                  H.ptr(dtt), ntok, Hd, ctx.pad_id, H.dt(dz), H.stream()), "fcmf_embed_bwd")
         if two_d:      # [sequences, S] layout: position rows are shared by the offsets of all sequences
             H.check(L.fcmf_embed_pos_bwd(H.ptr(dz), H.ptr(pos), H.ptr(dpos), ids.shape[0], ids.shape[1], Hd, ctx.pad_id,

@@ -360,3 +360,32 @@ def test_bare_bench_command_launches_its_own_ranks():
         r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "nccl", "--launch-check"], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_grad_arena_slack_rows_behind_a_ragged_vocabulary_matrix():
+    """GradArena pad_rows / take_rows: a large 2-D parameter whose row count is no multiple of 32 (the 64001-row tied vocabulary matrix)
+    gets zeroed slack rows behind its slice; the first producer that writes whole 32-row groups gets a [rows32, cols] buffer that starts
+    at the slice and hands autograd the slice itself, a later producer of the same pass gets the buffer and None (accumulate in place);
+    the next parameter's slice starts behind the slack.  CPU, no kernels."""
+    sys.path.insert(0, PKG)
+    from fcmf_framework.dp import ALIGN, GradArena
+    a = torch.nn.Parameter(torch.randn(8201, 4))
+    b = torch.nn.Parameter(torch.randn(16, 4))
+    arena = GradArena([b, a])               # backward order: a first, then b
+    try:
+        rows32 = (8201 + 31) // 32 * 32
+        assert arena.slack[id(a)] == (rows32 - 8201) * 4 and id(b) not in arena.slack
+        assert arena.offset[id(b)] >= arena.offset[id(a)] + rows32 * 4 and arena.offset[id(b)] % ALIGN == 0
+        assert arena.take_rows(a, rows32 + 32) is None                      # more rows than the slack covers
+        buf, ret = arena.take_rows(a, rows32)
+        assert tuple(buf.shape) == (rows32, 4) and buf.data_ptr() == arena.view[id(a)].data_ptr()
+        assert ret.data_ptr() == arena.view[id(a)].data_ptr() and ret is not arena.view[id(a)] and ret.shape == a.shape
+        buf2, ret2 = arena.take_rows(a, rows32)                              # a second producer of the same pass
+        assert buf2.data_ptr() == buf.data_ptr() and ret2 is None
+        assert arena.take(a) is None and arena.retake(a) is not None
+        buf.fill_(1.0)
+        arena.zero()
+        assert float(arena.flat.abs().sum()) == 0.0                          # the slack is zeroed with the slices
+        assert arena.take_rows(b, 32) is None                                # small parameters have no slack
+    finally:
+        arena.deactivate()

@@ -1298,3 +1298,30 @@ def test_head_nk_groupings_of_the_same_parameter_stay_fresh(dev):
         assert torch.equal(ops.shadows.head_nk([wk, wq]), want([wk, wq])) and torch.equal(ops.shadows.head_nk([wk]), want([wk]))
     finally:
         ops.shadows.clear()
+
+
+@pytest.mark.parametrize("nparams,tokens", [(2, 768), (1, 960), (12, 1000)])
+def test_gemm_colblocks_writes_per_head_weight_gradients_in_the_parameter_layout(dev, nparams, tokens):
+    """fcmf_gemm_colblocks: dW^T [E, n * n_head * d] = x^T dY with the column-blocked output (block = d, block stride = E * d, row
+    stride = d) IS the [n, n_head, E, d] layout of the IAOG decoder's per-head projection weights (mm_modeling.py:57-58, autograd of
+    :79-92): against the float64 product and against the plain fcmf_gemm + permute it replaces; a shape the blocked path refuses
+    returns FCMF_ERR_UNSUPPORTED (callers fall back)."""
+    ops, H = _ops()
+    nh, E, d = 12, 768, 64
+    N = nparams * nh * d
+    x = _rand((tokens, E), dev, torch.bfloat16, seed=1)
+    dy = _rand((tokens, N), dev, torch.bfloat16, 0.3, seed=2)
+    out = torch.full((nparams, nh, E, d), float("nan"), device=dev)
+    ctx = H.gemm_ctx(workspace=True)
+    H.check(H.lib().fcmf_gemm_colblocks(ctx, H.ptr(x), H.ptr(dy), H.ptr(out), E, N, tokens, E, N, d, 1, 1, d, E * d, 0, H.stream()), "colblocks")
+    ref = (dy.double().cpu().t() @ x.double().cpu()).view(nparams, nh, d, E).permute(0, 1, 3, 2)      # [n, nh, E, d]
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 2e-3
+    plain = torch.empty((N, E), device=dev)
+    ops.gemm(dy, x, plain, N, E, tokens, N, E, E, 1, 1)
+    assert rel_err(out, plain.view(nparams, nh, d, E).permute(0, 1, 3, 2)) < 1e-5
+    # accumulate into what is there
+    H.check(H.lib().fcmf_gemm_colblocks(ctx, H.ptr(x), H.ptr(dy), H.ptr(out), E, N, tokens, E, N, d, 1, 1, d, E * d, 1, H.stream()), "colblocks")
+    assert rel_err(out, 2 * ref) < 2e-3
+    small = torch.empty((1, 2, 128, 64), device=dev)     # E = 128 < 256: refused
+    assert H.lib().fcmf_gemm_colblocks(ctx, H.ptr(x), H.ptr(dy), H.ptr(small), 128, 128, tokens, E, N, d, 1, 1, d, 128 * d, 0, H.stream()) == H.ERR_UNSUPPORTED
