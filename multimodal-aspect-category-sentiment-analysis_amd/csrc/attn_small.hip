@@ -616,7 +616,9 @@ __global__ __launch_bounds__(256) void attn_private_grad_kernel(AttnK P) {
 // flat, fully parallel loops: thread = (row, key) for the scores, wave = row for the softmax, thread = (row, column) for the
 // outputs.  Same arithmetic, same dropout counters, same outputs as the general kernels.
 // =========================================================================================================================
-constexpr int TINY_MAX = 64;
+constexpr int TINY_MAX = 64;        // rows / keys of the one-block kernels
+constexpr int TINY_WIDE_MAX = 128;  // ... of the wide forward / row-blocked backward (LDS permitting)
+constexpr size_t TINY_LDS = 160 * 1024;
 
 __device__ __forceinline__ float dot_bf16_lds(const bf16_t* a, const bf16_t* b, int d) {      // d % 8 == 0, 16-byte aligned rows
   // v_dot2c_f32_bf16: two bf16 products added to an f32 accumulator per instruction, no conversions (two interleaved
@@ -633,6 +635,7 @@ __device__ __forceinline__ float dot_bf16_lds(const bf16_t* a, const bf16_t* b, 
   return s0 + s1;
 }
 
+template <bool WIDE>      // WIDE: 65..128 keys, two per lane in the softmax
 __global__ __launch_bounds__(256) void attn_tiny_fwd_kernel(AttnK P) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const fcmf_attn_desc& a = P.a;
@@ -664,13 +667,21 @@ __global__ __launch_bounds__(256) void attn_tiny_fwd_kernel(AttnK P) {
   const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
   for (int r = w; r < R; r += 4) {
     const float s = lane < T ? Ss[r * TP + lane] : -INFINITY;
-    const float m = wave_max(s);
+    float s1 = -INFINITY;
+    if (WIDE) s1 = lane + 64 < T ? Ss[r * TP + lane + 64] : -INFINITY;
+    const float m = wave_max(WIDE ? fmaxf(s, s1) : s);
     const float e = lane < T ? __expf(s - m) : 0.f;
-    const float sum = wave_sum(e);
+    const float e1 = WIDE && lane + 64 < T ? __expf(s1 - m) : 0.f;
+    const float sum = wave_sum(WIDE ? e + e1 : e);
     if (lane < T) {
       float pv = e / sum;
       if (a.dropout_p > 0.f) pv *= dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + lane, a.dropout_p, inv_keep);
       Ss[r * TP + lane] = pv;
+    }
+    if (WIDE && lane + 64 < T) {
+      float pv = e1 / sum;
+      if (a.dropout_p > 0.f) pv *= dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + lane + 64, a.dropout_p, inv_keep);
+      Ss[r * TP + lane + 64] = pv;
     }
     if (lane == 0 && P.lse) P.lse[((int64_t)g * a.heads + h) * R + r] = m + __logf(sum);
   }
@@ -718,7 +729,10 @@ __global__ __launch_bounds__(256) void attn_tiny_bwd_kernel(AttnK P) {
     float add = 0.f;
     if (a.mask) add = a.mask[(int64_t)g * T + t];
     if (a.bias) add += a.bias[(((int64_t)g2 * a.heads + h) * R) * T + idx];
-    DS[r * TP + t] = add - P.lse[((int64_t)g * a.heads + h) * R + r];      // score offset: + mask + bias - logsumexp
+    // score offset: + mask + bias - logsumexp (+inf marks a row whose every key carries the hard finfo.min mask: its
+    // logsumexp IS finfo.min -- log T is absorbed -- and its probabilities are uniform, as in the general kernel)
+    const float lse_r = P.lse[((int64_t)g * a.heads + h) * R + r];
+    DS[r * TP + t] = lse_r <= -1e30f ? INFINITY : add - lse_r;
   }
   for (int r = w; r < R; r += 4) {                       // delta[r] straight from global memory (dO, O rows)
     const bf16_t* orow = O + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
@@ -734,7 +748,8 @@ __global__ __launch_bounds__(256) void attn_tiny_bwd_kernel(AttnK P) {
     const int r = idx / T, t = idx - r * T;
     const float s = dot_bf16_lds(Qs + r * dp, Ks + t * dp, d) * a.scale;
     const float dpd = dot_bf16_lds(dOs + r * dp, Vs + t * dp, d);
-    const float pr = __expf(s + DS[r * TP + t]);          // (staged by this same thread: + mask + bias - logsumexp)
+    const float off = DS[r * TP + t];                     // (staged by this same thread: + mask + bias - logsumexp)
+    const float pr = off == INFINITY ? 1.0f / (float)T : __expf(s + off);
     float mult = 1.0f;
     if (a.dropout_p > 0.f) mult = dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + t, a.dropout_p, inv_keep);
     const float dsv = pr * (dpd * mult - dl[r]);
@@ -778,10 +793,122 @@ __global__ __launch_bounds__(256) void attn_tiny_bwd_kernel(AttnK P) {
   }
 }
 
+// The same backward for geometries whose two [R][T] f32 arrays no longer fit beside the operands (FCMF-large's ROI box
+// attention: 100 x 100, heads of 128 -> 190 KB): the query rows go through the score / dQ phases in blocks of RBK rows, and
+// each thread keeps its (key, 8 columns) dK / dV sums in registers across the blocks (NI = 8 items of 16 floats: T * d / 8
+// <= 2048 items over 256 threads).  Rows in ascending order inside and across blocks: the sums are the ones the
+// one-block kernel forms.
+__global__ __launch_bounds__(256) void attn_tiny_bwd_blocked_kernel(AttnK P) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NI = 8;
+  const fcmf_attn_desc& a = P.a;
+  const int d = a.d, T = a.T1, R = a.R, dp = d + 8, TP = T + 1, RBK = P.RB;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(sm);
+  bf16_t* dOs = Qs + R * dp;
+  bf16_t* Ks = dOs + R * dp;
+  bf16_t* Vs = Ks + T * dp;
+  float* PD = reinterpret_cast<float*>(Vs + T * dp);     // [RBK][TP] dropped probabilities of the current row block
+  float* DS = PD + RBK * TP;                             // [RBK][TP] score gradients
+  float* dl = DS + RBK * TP;                             // [R] delta = <dO, O>
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = blockIdx.x / a.heads, h = blockIdx.x % a.heads, g2 = g / a.group_div;
+  const int64_t HD = (int64_t)a.heads * d;
+  const bf16_t* dO = reinterpret_cast<const bf16_t*>(P.dout);
+  const bf16_t* O = reinterpret_cast<const bf16_t*>(P.o_in);
+  stage_rows<bf16_t, bf16_t>(Qs, dp, reinterpret_cast<const bf16_t*>(a.q) + (int64_t)g * a.q_sg + h * d, a.q_sr, R, d, w, lane);
+  stage_rows<bf16_t, bf16_t>(dOs, dp, dO + (int64_t)g * a.o_sg + h * d, a.o_sr, R, d, w, lane);
+  stage_rows<bf16_t, bf16_t>(Ks, dp, reinterpret_cast<const bf16_t*>(a.k1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T, d, w, lane);
+  stage_rows<bf16_t, bf16_t>(Vs, dp, reinterpret_cast<const bf16_t*>(a.v1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T, d, w, lane);
+  for (int r = w; r < R; r += 4) {
+    const bf16_t* orow = O + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
+    const bf16_t* drow = dO + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
+    float part = 0.f;
+    for (int c = lane; c < d; c += 64) part += (float)drow[c] * (float)orow[c];
+    part = wave_sum(part);
+    if (lane == 0) dl[r] = part;
+  }
+  const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  bf16_t* dQ = reinterpret_cast<bf16_t*>(P.dq);
+  bf16_t* dK = reinterpret_cast<bf16_t*>(P.dk1);
+  bf16_t* dV = reinterpret_cast<bf16_t*>(P.dv1);
+  const int d8 = d >> 3, nkv = T * d8;
+  float kacc[NI][8], vacc[NI][8];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kacc[i][j] = 0.f; vacc[i][j] = 0.f; }
+  for (int r0 = 0; r0 < R; r0 += RBK) {
+    const int rb = R - r0 < RBK ? R - r0 : RBK;
+    __syncthreads();                                     // operands + delta staged / the previous block's arrays read
+    for (int idx = tid; idx < rb * T; idx += 256) {      // additive terms of the block, all loads in flight together
+      const int rl = idx / T, t = idx - rl * T, r = r0 + rl;
+      float add = 0.f;
+      if (a.mask) add = a.mask[(int64_t)g * T + t];
+      if (a.bias) add += a.bias[(((int64_t)g2 * a.heads + h) * R + r) * T + t];
+      const float lse_r = P.lse[((int64_t)g * a.heads + h) * R + r];
+      DS[rl * TP + t] = lse_r <= -1e30f ? INFINITY : add - lse_r;      // (+inf: fully masked row, see the one-block kernel)
+    }
+    for (int idx = tid; idx < rb * T; idx += 256) {      // (same thread per element as the staging loop: no barrier)
+      const int rl = idx / T, t = idx - rl * T, r = r0 + rl;
+      const float s = dot_bf16_lds(Qs + r * dp, Ks + t * dp, d) * a.scale;
+      const float dpd = dot_bf16_lds(dOs + r * dp, Vs + t * dp, d);
+      const float off = DS[rl * TP + t];
+      const float pr = off == INFINITY ? 1.0f / (float)T : __expf(s + off);
+      float mult = 1.0f;
+      if (a.dropout_p > 0.f) mult = dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + t, a.dropout_p, inv_keep);
+      const float dsv = pr * (dpd * mult - dl[r]);
+      PD[rl * TP + t] = pr * mult;
+      DS[rl * TP + t] = dsv;
+      if (P.dbias) P.dbias[(((int64_t)g * a.heads + h) * R + r) * T + t] = dsv;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rb * d8; idx += 256) {     // dQ rows of the block: thread = (row, 8 columns)
+      const int rl = idx / d8, c = (idx - rl * d8) * 8;
+      float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < T; ++t) {
+        const float dsv = DS[rl * TP + t];
+        const bf16x8 kk = *reinterpret_cast<const bf16x8*>(Ks + t * dp + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] += dsv * (float)kk[j];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(q[j] * a.scale);
+      *reinterpret_cast<bf16x8*>(dQ + ((int64_t)g * R + r0 + rl) * HD + h * d + c) = o;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {                       // dK / dV partial sums: thread = (key, 8 columns), in registers
+      const int idx = tid + 256 * i;
+      if (idx < nkv) {
+        const int t = idx / d8, c = (idx - t * d8) * 8;
+        for (int rl = 0; rl < rb; ++rl) {
+          const float dsv = DS[rl * TP + t], pv = PD[rl * TP + t];
+          const bf16x8 qq = *reinterpret_cast<const bf16x8*>(Qs + (r0 + rl) * dp + c);
+          const bf16x8 gg = *reinterpret_cast<const bf16x8*>(dOs + (r0 + rl) * dp + c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { kacc[i][j] += dsv * (float)qq[j]; vacc[i][j] += pv * (float)gg[j]; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < nkv) {
+      const int t = idx / d8, c = (idx - t * d8) * 8;
+      bf16x8 ok, ov;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ok[j] = (bf16_t)(kacc[i][j] * a.scale); ov[j] = (bf16_t)vacc[i][j]; }
+      *reinterpret_cast<bf16x8*>(dK + ((int64_t)g * T + t) * HD + h * d + c) = ok;
+      *reinterpret_cast<bf16x8*>(dV + ((int64_t)g * T + t) * HD + h * d + c) = ov;
+    }
+  }
+}
+
 // the tiny kernels' preconditions (host)
 static bool tiny_ok(const fcmf_attn_desc* a) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  return a->dtype == FCMF_BF16 && a->T2 == 0 && a->T1 > 0 && a->T1 <= TINY_MAX && a->R <= TINY_MAX && !a->causal && !a->head_quirk &&
+  return a->dtype == FCMF_BF16 && a->T2 == 0 && a->T1 > 0 && a->T1 <= TINY_WIDE_MAX && a->R <= TINY_WIDE_MAX && !a->causal && !a->head_quirk &&
          a->d % 8 == 0 && a->q_sr % 8 == 0 && a->q_sg % 8 == 0 && a->k1_st % 8 == 0 && a->k1_sg % 8 == 0 && a->o_sr % 8 == 0 &&
          a->o_sg % 8 == 0 && al16(a->q) && al16(a->k1) && al16(a->v1);      // (+ 16-byte aligned outputs: checked by the callers)
 }
@@ -817,10 +944,13 @@ extern "C" int fcmf_attn_small_fwd(const fcmf_attn_desc* desc, void* out, float*
   if (tiny_ok(desc) && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     const int dp = desc->d + 8;
     const size_t smem = (size_t)(desc->R + 2 * desc->T1) * dp * 2 + sizeof(float) * (size_t)desc->R * (desc->T1 + 1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_tiny_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(attn_tiny_fwd_kernel, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
-    FCMF_CHECK_LAUNCH();
-    return FCMF_OK;
+    if (smem <= TINY_LDS) {
+      auto k = desc->T1 > 64 ? attn_tiny_fwd_kernel<true> : attn_tiny_fwd_kernel<false>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(k, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+      FCMF_CHECK_LAUNCH();
+      return FCMF_OK;
+    }
   }
   const size_t esz = desc->dtype == FCMF_F32 ? 4 : 2;
   P.KVF = (int)((2 * (size_t)desc->T1 * (desc->d + 16 / esz) * esz + 15) / 16 * 4);   // K and V images, rounded to 16 B, in floats
@@ -876,12 +1006,25 @@ static int attn_small_bwd_impl(const fcmf_attn_desc* desc, const void* out, cons
       ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) |
         reinterpret_cast<uintptr_t>(dk1) | reinterpret_cast<uintptr_t>(dv1)) & 15) == 0) {
     const int dp = desc->d + 8;
-    const size_t smem = (size_t)(2 * desc->R + 2 * desc->T1) * dp * 2 +
-                        sizeof(float) * ((size_t)2 * desc->R * (desc->T1 + 1) + desc->R);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_tiny_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(attn_tiny_bwd_kernel, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
-    FCMF_CHECK_LAUNCH();
-    return FCMF_OK;
+    const size_t opnd = (size_t)(2 * desc->R + 2 * desc->T1) * dp * 2 + sizeof(float) * (size_t)desc->R;
+    const size_t row = sizeof(float) * 2 * (size_t)(desc->T1 + 1);      // one row of the two [rows][T + 1] f32 arrays
+    if (desc->R <= TINY_MAX && desc->T1 <= TINY_MAX && opnd + desc->R * row <= TINY_LDS) {
+      const size_t smem = opnd + desc->R * row;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_tiny_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(attn_tiny_bwd_kernel, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+      FCMF_CHECK_LAUNCH();
+      return FCMF_OK;
+    }
+    if (opnd + 16 * row <= TINY_LDS) {                   // row blocks of >= 16 rows, as even as the LDS allows
+      const int fit = (int)((TINY_LDS - opnd) / row);
+      const int nblk = (desc->R + fit - 1) / fit;
+      P.RB = (desc->R + nblk - 1) / nblk;
+      const size_t smem = opnd + P.RB * row;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_tiny_bwd_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(attn_tiny_bwd_blocked_kernel, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+      FCMF_CHECK_LAUNCH();
+      return FCMF_OK;
+    }
   }
   const int nsh = desc->T1 < 128 ? desc->T1 : 128;
   const size_t esz = desc->dtype == FCMF_F32 ? 4 : 2;

@@ -419,7 +419,14 @@ ATTN_CASES = [
     (4, 36, 8, 96, 36, 0, 1, False, True, False),     # the step's ROI box attention (bf16: the all-in-LDS "tiny dense" kernels)
     (4, 36, 8, 96, 36, 0, 2, True, True, False),      # the same with a key mask and a bias shared by groups of 2
     (2, 64, 2, 64, 64, 0, 1, True, False, False),     # the tiny kernels' limits: 64 rows x 64 keys
-    (2, 65, 2, 64, 64, 0, 1, True, False, False),     # one row more: back on the general kernel
+    (2, 65, 2, 64, 64, 0, 1, True, False, False),     # one row more: the wide forward / row-blocked backward (one block)
+    (2, 100, 8, 128, 100, 0, 1, False, True, False),  # FCMF-large's ROI box attention: 100 x 100, heads of 128 (two row blocks)
+    (4, 100, 2, 128, 100, 0, 2, True, True, False),   # the same with a key mask and a bias shared by groups of 2
+    (2, 128, 2, 64, 128, 0, 1, True, True, False),    # the wide kernels' limits: 128 rows x 128 keys
+    (2, 128, 1, 128, 128, 0, 1, True, False, False),  # ... with heads of 128: the backward in three row blocks (forward: general kernel)
+    (2, 30, 2, 96, 100, 0, 1, True, True, False),     # few rows, > 64 keys
+    (2, 100, 2, 96, 30, 0, 1, False, True, False),    # > 64 rows, few keys
+    (2, 129, 2, 64, 64, 0, 1, True, False, False),    # one row more than the wide limit: the general kernel
 ]
 
 
@@ -458,11 +465,12 @@ def test_attention_fwd_bwd(dev, dtype, case):
             assert rel_err(a.grad, b.grad) < tol * 2, name
 
 
-def test_attention_tiny_dropout_consistent(dev):
-    """the all-in-LDS kernels (bf16, <= 64 rows / keys): with V = I the output IS the dropped probability matrix; kept entries
-    are the plain probabilities / (1 - p), and the backward uses the same mask (dV = P_drop^T dO)."""
+@pytest.mark.parametrize("R,T", [(16, 16), (100, 104), (128, 128)])
+def test_attention_tiny_dropout_consistent(dev, R, T):
+    """the all-in-LDS kernels (bf16, <= 64 rows / keys; wide / row-blocked up to 128): with V = I the output IS the dropped
+    probability matrix; kept entries are the plain probabilities / (1 - p), and the backward uses the same mask (dV = P_drop^T dO)."""
     ops, H = _ops()
-    G, R, T, p = 6, 16, 16, 0.3
+    G, p = 6, 0.3
     q = _rand((G, R, T), dev, torch.bfloat16, seed=1)
     k = _rand((G, T, T), dev, torch.bfloat16, seed=2)
     v = torch.eye(T, device=dev, dtype=torch.bfloat16).expand(G, T, T).contiguous().requires_grad_(True)
@@ -882,7 +890,7 @@ def test_attention_mfma_padded_sequences_skip_is_exact(dev, T, p):
         assert not res[True][2][g, l:].any() and not res[True][3][g, l:].any()
 
 
-@pytest.mark.parametrize("T", [128, 100])
+@pytest.mark.parametrize("T", [128, 100, 48])      # (48: the VALU leg runs the one-block all-in-LDS kernels)
 def test_attention_mfma_fully_masked_sequence_is_uniform(dev, T):
     """a sequence whose EVERY key carries the hard (finfo.min) mask: torch / the reference absorb the scores into finfo.min
     and softmax is uniform over all T keys (HF eager attention, modeling_roberta.py:158-183).  The MFMA kernels must not
