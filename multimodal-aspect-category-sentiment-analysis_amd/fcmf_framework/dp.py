@@ -229,10 +229,12 @@ class GradReducer:
                 batched kernel never ran under data parallelism.)  The collectives stay one per bucket, back to back.
     recheck_every: how often (in optimizer steps) the set of parameters that receive no gradient on any rank is
                 re-verified -- a parameter that turns live on SOME rank later raises on EVERY rank instead of
-                silently diverging replicas (round-2 advisor finding)."""
+                silently diverging replicas (round-2 advisor finding).
+    single_rank: run the whole machinery (hooks, buckets, collectives, mean) in a group of ONE rank as well instead of
+                short-circuiting it -- the RCCL path rehearsed on a one-GPU box (tests/test_dp_gpu.py)."""
 
     def __init__(self, arena, bucket_mb=32, process_group=None, overlap=True, exchange="fp32", native=False, recheck_every=50,
-                 group_mb=160):
+                 group_mb=160, single_rank=False):
         if not isinstance(arena, GradArena):                      # list of parameters (round-1 signature)
             arena = GradArena(list(arena))
         if exchange not in ("fp32", "bf16"):
@@ -241,6 +243,7 @@ class GradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.live = self.world > 1 or (single_rank and dist.is_initialized())
         self.params = arena.order
         self.overlap = overlap
         self.exchange = exchange
@@ -274,9 +277,9 @@ class GradReducer:
         self.group_log = []        # (first bucket, last bucket, parameters still without a local gradient) per group sent
         self._n_dead = [0] * len(self.buckets)
         self._native = None
-        if native and self.world > 1:
+        if native and self.live:
             self._native = _NativeComm(self.world, self.rank, self.group, arena.flat.device)
-        if self.world > 1:
+        if self.live:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         arena.on_zero.append(self.reset)
@@ -407,7 +410,7 @@ class GradReducer:
     def finish(self):
         """after backward: flush buckets whose gradients never all arrived, wait for the collectives and leave the
         MEAN in the arena (p.grad of every parameter that received a gradient on ANY rank is its arena slice)."""
-        if self.world == 1:
+        if not self.live:
             return
         self._launch_in_order(flush=True)
         cuda = self.arena.flat.is_cuda
@@ -461,7 +464,7 @@ class GradReducer:
 
     def broadcast_parameters(self, src=0):
         """replicate rank `src`'s parameters (what DDP does at wrap time)"""
-        if self.world == 1:
+        if not self.live:
             return
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.group)
