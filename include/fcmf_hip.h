@@ -255,6 +255,19 @@ int fcmf_xent_bwd(const void* logits, int64_t ld, const int64_t* labels, void* d
                   int64_t ldd, const float* scale_ptr, float extra_scale, int n, int C,
                   int64_t ignore_index, int dtype, void* stream);
 
+/* The reduction of CrossEntropyLoss(reduction="mean") (run_multimodal_fcmf.py:290,474) over fcmf_xent_fwd's rows, times
+ * `mult` (the driver sums the 6 aspects' batch means, :463-475 = mean over all rows x 6), in one fixed-order pass:
+ * out2[0] = mult * sum(loss_rows) / #(labels != ignore_index), out2[1] = mult / #(...) -- the scale of fcmf_xent_bwd. */
+int fcmf_xent_mean(const float* loss_rows, const int64_t* labels, int n, int64_t ignore_index,
+                   float mult, float* out2, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Additive attention mask of a 0 / 1 int64 mask [rows, >= cols] with row stride ld (elements):
+ * out[r][c] = (1 - mask[r][c]) * value as float32 [rows, cols]  (fcmf_pretraining.py:53-56,97-100,133-136: value = -10000;
+ * HF get_extended_attention_mask for the text encoder: value = finfo(float32).min). */
+int fcmf_additive_mask(const int64_t* mask, int64_t ld, float* out, int rows, int cols, float value,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * elementwise helpers */
 int fcmf_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);

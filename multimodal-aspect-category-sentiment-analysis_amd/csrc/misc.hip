@@ -25,6 +25,38 @@ __global__ __launch_bounds__(256) void xent_fwd_kernel(const T* __restrict__ log
   }
 }
 
+// mean over the non-ignored rows (x mult) and the backward's per-row scale, by ONE workgroup in a fixed order (f64 partial sums):
+// out2[0] = mult * sum(loss_rows) / nvalid, out2[1] = mult / nvalid  (0 / 0 = NaN when every row is ignored, as torch)
+__global__ __launch_bounds__(256) void xent_mean_kernel(const float* __restrict__ loss_rows, const int64_t* __restrict__ labels,
+                                                        int n, int64_t ignore_index, float mult, float* __restrict__ out2) {
+  __shared__ double ssum[256];
+  __shared__ int scnt[256];
+  double s = 0.0;
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += 256)
+    if (labels[i] != ignore_index) { s += (double)loss_rows[i]; ++c; }
+  ssum[threadIdx.x] = s; scnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) { ssum[threadIdx.x] += ssum[threadIdx.x + h]; scnt[threadIdx.x] += scnt[threadIdx.x + h]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float nv = (float)scnt[0];
+    out2[0] = mult * ((float)ssum[0] / nv);
+    out2[1] = mult / nv;
+  }
+}
+
+// additive attention mask from a 0 / 1 integer mask: out[r][c] = (mask[r][c] - 1) * (-value)  (= (1 - mask) * value)
+__global__ __launch_bounds__(256) void additive_mask_kernel(const int64_t* __restrict__ mask, int64_t ld, float* __restrict__ out,
+                                                            int rows, int cols, float value) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  out[i] = (float)(mask[(int64_t)r * ld + c] - 1) * (-value);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void xent_bwd_kernel(const T* __restrict__ logits, int64_t ld,
                                                        const int64_t* __restrict__ labels, T* __restrict__ dlogits,
@@ -375,6 +407,25 @@ extern "C" int fcmf_xent_fwd(const void* logits, int64_t ld, const int64_t* labe
   if (dtype == FCMF_F32) hipLaunchKernelGGL((xent_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)logits, ld, labels, loss_rows, nvalid, n, C, ignore_index);
   else if (dtype == FCMF_BF16) hipLaunchKernelGGL((xent_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)logits, ld, labels, loss_rows, nvalid, n, C, ignore_index);
   else return FCMF_ERR_UNSUPPORTED;
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_xent_mean(const float* loss_rows, const int64_t* labels, int n, int64_t ignore_index, float mult,
+                              float* out2, void* stream) {
+  if (!loss_rows || !labels || !out2 || n < 0) return FCMF_ERR_ARG;
+  hipLaunchKernelGGL(xent_mean_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), loss_rows, labels, n,
+                     ignore_index, mult, out2);
+  FCMF_CHECK_LAUNCH();
+  return FCMF_OK;
+}
+
+extern "C" int fcmf_additive_mask(const int64_t* mask, int64_t ld, float* out, int rows, int cols, float value, void* stream) {
+  if (!mask || !out || rows < 0 || cols < 0 || ld < cols) return FCMF_ERR_ARG;
+  if (rows == 0 || cols == 0) return FCMF_OK;
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(additive_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     mask, ld, out, rows, cols, value);
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
 }

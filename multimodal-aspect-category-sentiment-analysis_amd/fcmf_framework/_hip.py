@@ -66,6 +66,8 @@ SIGNATURES = {
     "fcmf_box_embedding": [_vp, _i, _vp, _vp, _i, _i, _vp],
     "fcmf_xent_fwd": [_vp, _i64, _vp, _vp, _vp, _i, _i, _i64, _i, _vp],
     "fcmf_xent_bwd": [_vp, _i64, _vp, _vp, _i64, _vp, _f, _i, _i, _i64, _i, _vp],
+    "fcmf_xent_mean": [_vp, _vp, _i, _i64, _f, _vp, _vp],
+    "fcmf_additive_mask": [_vp, _i64, _vp, _i, _i, _f, _vp],
     "fcmf_cast": [_vp, _vp, _i64, _i, _i, _vp],
     "fcmf_cast_transpose": [_vp, _vp, _i, _i, _vp],
     "fcmf_multi_cast_transpose": [_vp, _vp, _vp, _vp, _i, _vp],

@@ -66,4 +66,4 @@ class FCMF(nn.Module):
         """sum over aspects of the batch-mean CE (run_multimodal_fcmf.py:463-475), in one kernel:
         mean over B*A rows times A."""
         B, A, C = logits.shape
-        return ops.cross_entropy(logits.reshape(B * A, C), labels.reshape(B * A)) * A
+        return ops.cross_entropy(logits.reshape(B * A, C), labels.reshape(B * A), mult=float(A))

@@ -16,7 +16,9 @@ def additive_mask(mask01, length, value=-10000.0):
     m = mask01[:, :length]
     if m.dtype.is_floating_point:
         return (1.0 - m.to(torch.float32)) * value
-    return (m - 1) * (-float(value))        # integer 0 / 1 masks: the same values ((1 - m) * value exactly) in two launches instead of three
+    if m.is_cuda and m.dtype == torch.int64 and m.dim() == 2 and m.stride(1) == 1:
+        return ops.additive_mask(m, float(value))                           # one launch, no torch arithmetic
+    return (m - 1) * (-float(value))        # integer 0 / 1 masks: the same values ((1 - m) * value exactly)
 
 
 def attn_sublayer_params(mod):

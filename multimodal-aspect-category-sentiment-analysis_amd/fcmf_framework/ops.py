@@ -1122,7 +1122,8 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k1, v1, k2, v2, mask, bias, heads, group_div, scale, p, seed, causal):
         H.require_cuda(q)
-        q = q if q.stride(2) == 1 and q.stride(1) >= q.shape[2] else q.contiguous()
+        # (row stride 0 = one query row expanded over R rows -- the [CLS] query against every image's keys: read in place)
+        q = q if q.stride(2) == 1 and (q.stride(1) >= q.shape[2] or q.stride(1) == 0) else q.contiguous()
         k1 = None if k1 is None else (k1 if k1.stride(2) == 1 else k1.contiguous())
         v1 = None if v1 is None else (v1 if v1.stride() == k1.stride() else v1.contiguous())
         if k1 is not None and v1.stride() != k1.stride():
@@ -1295,34 +1296,45 @@ def box_embedding(coords):
 # cross entropy
 # --------------------------------------------------------------------------------------
 class XentFn(torch.autograd.Function):
-    """mean cross entropy over the non-ignored rows (torch.nn.CrossEntropyLoss semantics)"""
+    """mean cross entropy over the non-ignored rows (torch.nn.CrossEntropyLoss semantics) x `mult`: rows, their mean and the
+    backward's scale in two launches, no torch arithmetic (fcmf_xent_fwd + fcmf_xent_mean)"""
 
     @staticmethod
-    def forward(ctx, logits, labels, ignore_index):
+    def forward(ctx, logits, labels, ignore_index, mult):
         lg = logits if logits.stride(-1) == 1 else logits.contiguous()
         lg = lg.reshape(-1, lg.shape[-1]) if lg.dim() != 2 else lg
         lb = labels.reshape(-1).contiguous()
         H.require_cuda(lg, lb)
         n, C = lg.shape
         rows = torch.empty(n, dtype=torch.float32, device=lg.device)
-        nvalid = torch.zeros(1, dtype=torch.float32, device=lg.device)
-        H.check(H.lib().fcmf_xent_fwd(H.ptr(lg), lg.stride(0), H.ptr(lb), H.ptr(rows), H.ptr(nvalid), n, C, ignore_index,
-                                      H.dt(lg), H.stream()), "fcmf_xent_fwd")
-        ctx.save_for_backward(lg, lb, nvalid)
+        out2 = torch.empty(2, dtype=torch.float32, device=lg.device)       # [loss, mult / nvalid]
+        L = H.lib()
+        H.check(L.fcmf_xent_fwd(H.ptr(lg), lg.stride(0), H.ptr(lb), H.ptr(rows), None, n, C, ignore_index, H.dt(lg), H.stream()),
+                "fcmf_xent_fwd")
+        H.check(L.fcmf_xent_mean(H.ptr(rows), H.ptr(lb), n, ignore_index, float(mult), H.ptr(out2), H.stream()), "fcmf_xent_mean")
+        ctx.save_for_backward(lg, lb, out2)
         ctx.ignore_index = ignore_index
         ctx.lshape = logits.shape
-        return rows.sum() / nvalid[0]
+        return out2[0]
 
     @staticmethod
     def backward(ctx, g):
-        lg, lb, nvalid = ctx.saved_tensors
+        lg, lb, out2 = ctx.saved_tensors
         n, C = lg.shape
         d = torch.empty((n, C), dtype=lg.dtype, device=lg.device)
-        scale = (g.float() / nvalid[0]).reshape(1).contiguous()
+        scale = (g.float() * out2[1]).reshape(1)
         H.check(H.lib().fcmf_xent_bwd(H.ptr(lg), lg.stride(0), H.ptr(lb), H.ptr(d), C, H.ptr(scale), 1.0, n, C,
                                       ctx.ignore_index, H.dt(lg), H.stream()), "fcmf_xent_bwd")
-        return d.view(ctx.lshape), None, None
+        return d.view(ctx.lshape), None, None, None
 
 
-def cross_entropy(logits, labels, ignore_index=-100):
-    return XentFn.apply(logits, labels, int(ignore_index))
+def additive_mask(m, value):
+    """(m - 1) * (-value) as float32 for a 0 / 1 int64 mask [G, L] (row stride free): fcmf_additive_mask"""
+    G, Lc = m.shape
+    out = torch.empty((G, Lc), dtype=torch.float32, device=m.device)
+    H.check(H.lib().fcmf_additive_mask(H.ptr(m), m.stride(0), H.ptr(out), G, Lc, float(value), H.stream()), "fcmf_additive_mask")
+    return out
+
+
+def cross_entropy(logits, labels, ignore_index=-100, mult=1.0):
+    return XentFn.apply(logits, labels, int(ignore_index), float(mult))

@@ -465,6 +465,32 @@ def test_attention_fwd_bwd(dev, dtype, case):
             assert rel_err(a.grad, b.grad) < tol * 2, name
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_expanded_query_rows_read_in_place(dev, dtype):
+    """one query row per group expanded over R rows (row stride 0: the [CLS] query against each image's private keys,
+    fcmf_pretraining.py:84-93) is read in place: same output and gradients as the materialised copy, bit for bit"""
+    ops, H = _ops()
+    G, R, heads, d, T2, gd = 12, 7, 3, 64, 49, 6
+    HD = heads * d
+    q1 = _rand((G, HD), dev, dtype, 0.7, seed=1)
+    k2 = _rand((G // gd, R, T2, HD), dev, dtype, 0.7, seed=2)
+    v2 = _rand((G // gd, R, T2, HD), dev, dtype, 0.7, seed=3)
+    w = _rand((G, R, HD), dev, dtype, seed=4)
+    res = []
+    for materialise in (False, True):
+        qa = q1.clone().requires_grad_(True)
+        ka, va = k2.clone().requires_grad_(True), v2.clone().requires_grad_(True)
+        q = qa.unsqueeze(1).expand(G, R, HD)
+        assert q.stride(1) == 0
+        if materialise:
+            q = q.contiguous()
+        out = ops.attention(q, k2=ka, v2=va, heads=heads, group_div=gd)
+        (out.float() * w.float()).sum().backward()
+        res.append((out.detach(), qa.grad, ka.grad, va.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("R,T", [(16, 16), (100, 104), (128, 128)])
 def test_attention_tiny_dropout_consistent(dev, R, T):
     """the all-in-LDS kernels (bf16, <= 64 rows / keys; wide / row-blocked up to 128): with V = I the output IS the dropped
@@ -630,6 +656,44 @@ def test_cross_entropy(dev, dtype):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert abs(loss.item() - ref.item()) < tol * max(1, abs(ref.item()))
     assert rel_err(lg.grad, lr.grad) < tol * 2
+
+
+def test_cross_entropy_mult_and_all_ignored(dev):
+    """ops.cross_entropy(..., mult=A) = A x the mean over the non-ignored rows (the driver's sum of the 6 aspects' batch
+    means, run_multimodal_fcmf.py:463-475) with its gradient; every row ignored: NaN loss as torch, zero gradient rows"""
+    ops, H = _ops()
+    n, C, A = 384, 4, 6
+    lg = _rand((n, C), dev, torch.float32, 2.0, seed=1).requires_grad_(True)
+    lb = torch.randint(0, C, (n,), generator=torch.Generator().manual_seed(2))
+    lb[::7] = -100
+    loss = ops.cross_entropy(lg, lb.to(dev), mult=float(A))
+    (loss / 2).backward()
+    lr = lg.detach().cpu().double().requires_grad_(True)
+    ref = F.cross_entropy(lr, lb, ignore_index=-100) * A
+    (ref / 2).backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 * abs(ref.item())
+    assert rel_err(lg.grad, lr.grad) < 1e-6
+    lg2 = _rand((5, C), dev, torch.float32, 2.0, seed=3).requires_grad_(True)
+    dead = ops.cross_entropy(lg2, torch.full((5,), -100, device=dev))
+    assert torch.isnan(dead).item()
+    dead.backward()
+    assert not lg2.grad.any()
+
+
+@pytest.mark.parametrize("value", [-10000.0, float(torch.finfo(torch.float32).min)])
+def test_additive_mask_matches_torch_formula(dev, value):
+    """layers.additive_mask on an int64 0 / 1 mask (one launch, fcmf_additive_mask) == (1 - mask[:, :L]) * value, bit for
+    bit, for a leading slice of a wider mask (fcmf_pretraining.py:53-56,97-100,133-136; HF extended mask = finfo.min)"""
+    from fcmf_framework import layers
+    m = (torch.rand(37, 190, generator=torch.Generator().manual_seed(1)) > 0.3).long().to(dev)
+    for Lc in (190, 164, 49, 15, 1):
+        got = layers.additive_mask(m, Lc, value)
+        want = (1.0 - m[:, :Lc].float()) * value
+        assert got.dtype == torch.float32 and got.shape == (37, Lc)
+        assert torch.equal(got, want)
+    _, H = _ops()
+    out = torch.empty(4, device=dev)
+    assert H.lib().fcmf_additive_mask(H.ptr(m), 2, H.ptr(out), 1, 4, -1.0, 0) == -1      # row stride < columns
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
