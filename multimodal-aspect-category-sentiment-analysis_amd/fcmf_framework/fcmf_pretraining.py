@@ -20,6 +20,7 @@ import torch.nn as nn
 from . import layers, ops
 from .mm_modeling import *  # noqa: F401,F403  (reference does the same; exposes the constants)
 from .mm_modeling import BertCrossEncoder, BertPooler, FeatureExtractor, IAOGDecoder, MultimodalEncoder
+from .decoding import beam_search  # noqa: F401  (the reference keeps it in this module, :383-517, commented out)
 from .roi_modeling import *  # noqa: F401,F403
 from .roi_modeling import BoxMultiHeadedAttention
 

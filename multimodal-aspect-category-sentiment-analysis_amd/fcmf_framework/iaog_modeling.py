@@ -370,7 +370,12 @@ class IAOGDecoder(nn.Module):
     def init_state(self, enc_outputs, enc_valid_lens):
         return [enc_outputs, enc_valid_lens, [None] * self.num_blks]
 
-    def hidden_states(self, X, state, enc_attention_mask=None, is_train=True):
+    def project_encoder(self, enc_outputs):
+        """every block's cross-attention keys ( = values, mm_modeling.py:129) of an encoder output, one GEMM for all blocks;
+        hand the result to forward(..., hoisted=) when the same encoder output is decoded again and again (decoding.py)"""
+        return _HoistedKeysFn.apply(layers.to_compute(enc_outputs), *[blk.attention2.w_kx for blk in self.blks])
+
+    def hidden_states(self, X, state, enc_attention_mask=None, is_train=True, hoisted=None):
         """the decoder stack up to (not including) the vocabulary projection: [B, Ld, H]"""
         # embedding * sqrt(H) + P in one kernel, then PositionalEncoding's dropout (mm_modeling.py:650, :633)
         X = _ScaledEmbedding.apply(X, self.embedding.weight, self.pos_encoding.P, math.sqrt(self.num_hiddens), ops.compute_dtype())
@@ -378,7 +383,8 @@ class IAOGDecoder(nn.Module):
         self._attention_weights = [[None] * len(self.blks) for _ in range(2)]
         # every block's cross attention projects the SAME encoder output with its own w_kx: one GEMM for all of them
         enc = layers.to_compute(state[0])
-        hoisted = _HoistedKeysFn.apply(enc, *[blk.attention2.w_kx for blk in self.blks]) if enc.dim() == 3 else [None] * len(self.blks)
+        if hoisted is None:
+            hoisted = _HoistedKeysFn.apply(enc, *[blk.attention2.w_kx for blk in self.blks]) if enc.dim() == 3 else [None] * len(self.blks)
         for i, blk in enumerate(self.blks):
             blk._hoisted_kx = hoisted[i]
             try:
@@ -389,8 +395,8 @@ class IAOGDecoder(nn.Module):
             self._attention_weights[1][i] = blk.attention2.attention_weights
         return X
 
-    def forward(self, X, state, enc_attention_mask=None, is_train=True):
-        X = self.hidden_states(X, state, enc_attention_mask, is_train)
+    def forward(self, X, state, enc_attention_mask=None, is_train=True, hoisted=None):
+        X = self.hidden_states(X, state, enc_attention_mask, is_train, hoisted)
         return ops.vocab_linear(X, self.dense.weight, self.dense.bias)
 
     def loss(self, X, state, labels, enc_attention_mask=None, ignore_index=-100):

@@ -359,21 +359,60 @@ def positional_table(max_len, H):
 
 
 def iaog_decoder_forward(P, cfg, dec_X, enc_out, training=False, prefix="decoder",
-                         emb_key="decoder.embedding.weight", out_w_key="decoder.dense.weight"):
+                         emb_key="decoder.embedding.weight", out_w_key="decoder.dense.weight", is_train=True):
     """IAOGDecoder.forward mm_modeling.py:649-662 in teacher-forced training mode
     (is_train=True): causal self-attention, and -- because the encoder mask handed down is
-    2-D (fcmf_pretraining.py:184-199) -- the SAME tril rule on the cross attention."""
+    2-D (fcmf_pretraining.py:184-199) -- the SAME tril rule on the cross attention.
+    is_train=False (the decode call of the commented-out beam search, fcmf_pretraining.py:470): dec_valid_lens = None
+    (mm_modeling.py:595-596) and no encoder mask is handed down (cross_mask = enc_valid_lens = None, :606), so neither
+    attention is masked; the per-block cache state[2][i] stays None (:584-588 assign it only when it already is a tensor)."""
     H = cfg["hidden_size"]
     nh = cfg["num_attention_heads"]
+    causal = bool(is_train)
     x = P[emb_key][dec_X] * math.sqrt(H) + positional_table(512, H)[: dec_X.shape[1]].to(enc_out.dtype)
     x = dropout(x, 0.1, training)
     for i in range(cfg["num_hidden_layers"]):
         b = f"{prefix}.blks.block{i}"
-        x2 = iaog_attention(P, b + ".attention1", x, x, True, nh)                   # :601
+        x2 = iaog_attention(P, b + ".attention1", x, x, causal, nh)                 # :601
         y = tf_layer_norm(dropout(x2, 0.1, training) + x, P[b + ".addnorm1.ln.weight"], P[b + ".addnorm1.ln.bias"], 1e-12)
-        y2 = iaog_attention(P, b + ".attention2", enc_out, y, True, nh)             # :610
+        y2 = iaog_attention(P, b + ".attention2", enc_out, y, causal, nh)           # :610
         z = tf_layer_norm(dropout(y2, 0.1, training) + y, P[b + ".addnorm2.ln.weight"], P[b + ".addnorm2.ln.bias"], 1e-12)
         f = F.linear(gelu_erf(F.linear(z, P[b + ".ffn.dense1.weight"], P[b + ".ffn.dense1.bias"])),
                      P[b + ".ffn.dense2.weight"], P[b + ".ffn.dense2.bias"])
         x = tf_layer_norm(dropout(f, 0.1, training) + z, P[b + ".add_norm3.ln.weight"], P[b + ".add_norm3.ln.bias"], 1e-12)
     return F.linear(x, P[out_w_key], P[prefix + ".dense.bias"])                     # :662
+
+
+def beam_search_ids(step_logprobs, start_id, sep_id, beam_size=3, max_len=20):
+    """The beam search the reference keeps (commented out) in fcmf_pretraining.py:383-517, on token ids.
+    `step_logprobs(seq)` = log_softmax of the decoder's logits for the LAST token of `seq` (a list of ids) -- the
+    reference feeds ONLY that token ([1, 1], :452) to a decoder whose per-block cache is never filled, so the step sees
+    the last token at position 0 and the encoder output, nothing else.
+      beams start as [(0.0, [start])] (:430-436); per step every live beam is expanded by its top `beam_size` tokens
+      (:476-486); a beam whose last token is SEP moves to the finished list instead (:444-447); the candidates are
+      sorted by score, descending and stable (:493), the best `beam_size` survive (:497); all survivors finished ->
+      they are added to the finished list and the loop ends (:500-502); nothing finished by max_len -> the live beams
+      are the finished list (:505-506); the best finished sequence wins, first in list order on ties (:509).
+    Returns (ids of the best sequence incl. the start token, its score, the finished list [(score, ids)])."""
+    beams = [(0.0, [int(start_id)])]
+    final = []
+    for _ in range(max_len):
+        cands = []
+        for score, seq in beams:
+            if seq[-1] == sep_id:
+                final.append((score, seq))
+                continue
+            lp = step_logprobs(seq)
+            top_s, top_i = torch.topk(lp, beam_size)
+            for k in range(beam_size):
+                cands.append((score + top_s[k].item(), seq + [int(top_i[k])]))
+        if not cands:
+            break
+        beams = sorted(cands, key=lambda c: c[0], reverse=True)[:beam_size]
+        if all(seq[-1] == sep_id for _, seq in beams):
+            final.extend(beams)
+            break
+    if not final:
+        final = list(beams)
+    best_score, best_seq = sorted(final, key=lambda c: c[0], reverse=True)[0]
+    return best_seq, best_score, final

@@ -384,8 +384,72 @@ def iaog_fixture(tag="tiny", cfg=None, Bs=(3, 4), NI=2, NR=5, S=16, Ld=6, col_st
     print("iaog fixture ok", tag, os.path.getsize(os.path.join(GOLD, f"iaog_{tag}.npz")) // 1024, "KiB")
 
 
+def decode_fixture(NI=2, NR=5, S=16, max_len=8):
+    """IAOG decode path.  The beam-search FUNCTION sits inside a string literal in the reference
+    (fcmf_pretraining.py:380-517: commented out, as are its call sites run_pretraining_fcmf.py:405-414,523-533) and cannot be
+    imported.  What the reference import DOES pin here is the decoder step the loop is made of -- model.encoder(...) once,
+    init_state(enc, None), model.decoder([[last token]], state, is_train=False) (:404-418,436,470) -- and the fixture holds
+    the result of the oracle's restatement of the loop (fcmf_oracle.beam_search_ids) run over THAT reference step, for two
+    samples and two settings (beam 2 / SEP never produced; beam 3 / SEP = a token the chain produces, so beams finish)."""
+    cfg = synth.TINY_CFG
+    patch_constants(cfg)
+    from fcmf_framework.fcmf_pretraining import FCMFSeq2Seq
+    import torch.nn.functional as F
+    V = cfg["vocab_size"]
+    model = FCMFSeq2Seq(V, 20, make_hf_dir(cfg), NI, NR, 1.0)
+    model.decoder.embedding = torch.nn.Embedding(V, model.decoder.num_hiddens)      # run_pretraining_fcmf.py:189
+    shapes = {k: v for k, v in synth.fcmf_param_shapes(cfg).items() if k.startswith("encoder.")}
+    shapes.update(synth.iaog_decoder_param_shapes(cfg, V))
+    P, extra = load_synth_into(model, shapes)
+    model.eval()
+    Pw = dict(P)
+    Pw["decoder.dense.weight"] = Pw["encoder.bert.cell.embeddings.word_embeddings.weight"]
+    batch = synth.synth_batch(2, cfg, S=S, num_imgs=NI, num_roi=NR, seed=5, coord_dtype=torch.float32)
+    out = {"geometry": np.array([NI, NR, S, max_len])}
+    start = 0
+    for b in range(2):
+        sl = slice(b, b + 1)
+        args = (batch["input_ids"][sl, 0], batch["visual_embeds_att"][sl], batch["roi_embeds_att"][sl], batch["roi_coors"][sl],
+                batch["token_type_ids"][sl, 0], batch["attention_mask"][sl, 0], batch["added_attention_mask"][sl, 0])
+        with torch.no_grad():
+            enc = model.encoder(*args)
+            enc = enc[0] if isinstance(enc, tuple) else enc
+            oenc = O.fcmf_encoder_forward(Pw, cfg, *args, NI, NR)
+
+        def ref_logits(tok):
+            state = model.decoder.init_state(enc, None)
+            with torch.no_grad():
+                lg = model.decoder(torch.tensor([[tok]]), state, is_train=False)
+            assert all(c is None for c in state[2])           # the per-block cache is never filled
+            return lg[0, -1, :]
+
+        def ref_step(seq):
+            return F.log_softmax(ref_logits(seq[-1]), dim=-1)
+
+        for tok in (start, 7, 123):                            # the oracle's is_train=False step against the reference's
+            with torch.no_grad():
+                ol = O.iaog_decoder_forward(Pw, cfg, torch.tensor([[tok]]), oenc, is_train=False)[0, -1]
+            rl = ref_logits(tok)
+            err = (ol - rl).abs().max().item()
+            print(f"decode sample {b} token {tok}: oracle-vs-reference step logits {err:.2e}")
+            assert err < 1e-4
+            out[f"s{b}_logits_tok{tok}"] = rl.numpy()[::4]
+        ids_a, score_a, fin_a = O.beam_search_ids(ref_step, start, 2, beam_size=2, max_len=max_len)
+        sep_b = ids_a[3]
+        ids_b, score_b, fin_b = O.beam_search_ids(ref_step, start, sep_b, beam_size=3, max_len=max_len)
+        print(f"decode sample {b}: A ids {ids_a} score {score_a:.5f} | B (sep {sep_b}) ids {ids_b} score {score_b:.5f}, {len(fin_b)} finished")
+        out[f"s{b}_a_ids"], out[f"s{b}_a_score"] = np.array(ids_a), np.float64(score_a)
+        out[f"s{b}_a_final_scores"] = np.array([f[0] for f in fin_a])
+        out[f"s{b}_b_sep"] = np.int64(sep_b)
+        out[f"s{b}_b_ids"], out[f"s{b}_b_score"] = np.array(ids_b), np.float64(score_b)
+        out[f"s{b}_b_final_scores"] = np.array([f[0] for f in fin_b])
+        out[f"s{b}_b_final_lens"] = np.array([len(f[1]) for f in fin_b])
+    np.savez_compressed(os.path.join(GOLD, "iaog_decode.npz"), **out)
+    print("decode fixture ok", os.path.getsize(os.path.join(GOLD, "iaog_decode.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["box", "bertadam", "tiny", "iaog", "iaog_base", "base"]
+    which = sys.argv[1:] or ["box", "bertadam", "tiny", "iaog", "decode", "iaog_base", "base"]
     if "box" in which:
         box_fixture()
     if "bertadam" in which:
@@ -394,6 +458,8 @@ if __name__ == "__main__":
         fcmf_fixture("tiny", synth.TINY_CFG, B=3, S=16, NI=2, NR=5, store_all_grads=False)
     if "iaog" in which:
         iaog_fixture()
+    if "decode" in which:
+        decode_fixture()
     if "iaog_base" in which:
         iaog_fixture("base", synth.BASE_CFG, Bs=(3, 5), NI=7, NR=4, S=128, Ld=12, col_step=64)
     if "base" in which:

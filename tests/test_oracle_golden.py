@@ -1,6 +1,7 @@
 """The CPU oracle against the committed golden fixtures (outputs of the REFERENCE import,
 oracle/make_golden.py).  This is the pin that lets the oracle stand in for the reference on the GPU
 box, where /root/reference does not exist."""
+import math
 import os
 
 import numpy as np
@@ -147,3 +148,52 @@ def test_oracle_iaog_base_geometry_forward():
         assert (logits[:, :, ::step] - torch.from_numpy(z[t + "logits"])).abs().max() < 1e-4
         loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), torch.from_numpy(z[t + "labels"]), ignore_index=-100)
     assert abs(loss.item() - float(z[t + "loss"])) < 1e-4
+
+
+def test_oracle_iaog_decode_matches_reference_fixture():
+    """the oracle's decode path -- encoder, the decoder's is_train=False step (no mask on either attention, one token at
+    position 0), the restated beam search (fcmf_pretraining.py:383-517) -- against iaog_decode.npz: step logits of the
+    REFERENCE import and the beam search run over the reference's decoder step (oracle/make_golden.py decode_fixture)"""
+    z = np.load(os.path.join(GOLD, "iaog_decode.npz"))
+    NI, NR, S, max_len = (int(v) for v in z["geometry"])
+    cfg = synth.TINY_CFG
+    V = cfg["vocab_size"]
+    shapes = {k: v for k, v in synth.fcmf_param_shapes(cfg).items() if k.startswith("encoder.")}
+    shapes.update(synth.iaog_decoder_param_shapes(cfg, V))
+    P = dict(synth.synth_params(shapes))
+    P["decoder.dense.weight"] = P["encoder.bert.cell.embeddings.word_embeddings.weight"]
+    batch = synth.synth_batch(2, cfg, S=S, num_imgs=NI, num_roi=NR, seed=5, coord_dtype=torch.float32)
+    for b in range(2):
+        sl = slice(b, b + 1)
+        with torch.no_grad():
+            enc = O.fcmf_encoder_forward(P, cfg, batch["input_ids"][sl, 0], batch["visual_embeds_att"][sl], batch["roi_embeds_att"][sl],
+                                         batch["roi_coors"][sl], batch["token_type_ids"][sl, 0], batch["attention_mask"][sl, 0],
+                                         batch["added_attention_mask"][sl, 0], NI, NR)
+
+        def logits(tok):
+            with torch.no_grad():
+                return O.iaog_decoder_forward(P, cfg, torch.tensor([[tok]]), enc, is_train=False)[0, -1]
+
+        for tok in (0, 7, 123):
+            assert (logits(tok)[::4] - torch.from_numpy(z[f"s{b}_logits_tok{tok}"])).abs().max() < 1e-5
+        step = lambda seq: torch.log_softmax(logits(seq[-1]), dim=-1)
+        ids, score, fin = O.beam_search_ids(step, 0, 2, beam_size=2, max_len=max_len)
+        assert ids == z[f"s{b}_a_ids"].tolist() and abs(score - float(z[f"s{b}_a_score"])) < 1e-4
+        assert np.allclose([f[0] for f in fin], z[f"s{b}_a_final_scores"], atol=1e-4)
+        ids, score, fin = O.beam_search_ids(step, 0, int(z[f"s{b}_b_sep"]), beam_size=3, max_len=max_len)
+        assert ids == z[f"s{b}_b_ids"].tolist() and abs(score - float(z[f"s{b}_b_score"])) < 1e-4
+        assert [len(f[1]) for f in fin] == z[f"s{b}_b_final_lens"].tolist()
+        assert ids[-1] == int(z[f"s{b}_b_sep"]) and len(ids) < max_len + 1            # the finishing path was taken
+
+
+def test_oracle_beam_search_loop_rules():
+    """the loop's rules on a hand-made step function: stable descending sort, finished beams leave the search, all
+    survivors finished -> stop, nothing finished -> the live beams compete (fcmf_pretraining.py:444-447,493-509)"""
+    table = {0: [0.5, 0.3, 0.2, 0.0], 1: [0.1, 0.1, 0.1, 0.7], 2: [0.25, 0.25, 0.25, 0.25], 3: [0.0, 0.0, 0.0, 1.0]}
+    step = lambda seq: torch.log(torch.tensor(table[seq[-1]]) + 1e-30)
+    ids, score, fin = O.beam_search_ids(step, 0, 3, beam_size=2, max_len=6)
+    assert ids == [0, 1, 3] and abs(score - (math.log(0.3) + math.log(0.7))) < 1e-6
+    assert all(f[1][-1] == 3 for f in fin)
+    ids, score, fin = O.beam_search_ids(step, 0, 9, beam_size=2, max_len=3)          # SEP never produced
+    assert ids == [0, 1, 3, 3] and len(fin) == 2 and abs(score - (math.log(0.3) + math.log(0.7))) < 1e-6
+    assert fin[1][1] == [0, 0, 0, 0] and abs(fin[1][0] - 3 * math.log(0.5)) < 1e-6

@@ -716,6 +716,61 @@ def _iaog_forward(model, batch, dec):
                  batch["added_attention_mask"][:, 0], None, is_train=True)
 
 
+class _StubTokenizer:
+    """ids -> text stand-in (no tokenizer files offline): the attributes and the call the reference's beam search uses"""
+    bos_token_id, cls_token_id = None, 0
+
+    def __init__(self, sep):
+        self.sep_token_id = sep
+
+    def decode(self, ids, skip_special_tokens=True):
+        special = {self.cls_token_id, self.sep_token_id} if skip_special_tokens else set()
+        return " ".join(str(int(i)) for i in ids if int(i) not in special) + " "
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_iaog_beam_search_matches_reference_fixture(dev, dtype):
+    """fcmf_framework.decoding.beam_search (the reference's commented-out function, fcmf_pretraining.py:383-517)
+    against iaog_decode.npz: the decoder's is_train=False step logits of the REFERENCE import, and the token sequences /
+    scores of the restated loop run over the reference's decoder step -- SEP never produced (beams run to max_len) and SEP
+    produced (beams finish).  float32: same ids, scores within 1e-3; bf16: step logits within the bf16 bound and a
+    well-formed result (near-ties may legitimately order differently)."""
+    from fcmf_framework import decoding
+    z = np.load(os.path.join(GOLD, "iaog_decode.npz"))
+    NI, NR, S, max_len = (int(v) for v in z["geometry"])
+    model, batch = _iaog_model(dev, 2)
+    _set(dtype)
+    try:
+        for b in range(2):
+            sl = slice(b, b + 1)
+            args = (batch["input_ids"][sl, 0], batch["attention_mask"][sl, 0], batch["token_type_ids"][sl, 0],
+                    batch["added_attention_mask"][sl, 0], batch["visual_embeds_att"][sl], batch["roi_embeds_att"][sl], batch["roi_coors"][sl])
+            with torch.no_grad():
+                enc = model.encoder(args[0], args[4], args[5], args[6], args[2], args[1], args[3])
+                enc = enc[0] if isinstance(enc, tuple) else enc
+                for tok in (0, 7, 123):
+                    lg = model.decoder(torch.tensor([[tok]], device=dev), model.decoder.init_state(enc, None), is_train=False)
+                    ref = torch.from_numpy(z[f"s{b}_logits_tok{tok}"])
+                    tol = 1e-4 if dtype == torch.float32 else 0.05 * ref.abs().max().item()
+                    assert max_err(lg[0, -1, ::4].float(), ref) < tol, (b, tok)
+            ids, score, fin = decoding.beam_search_ids(model, 0, 2, *args, beam_size=2, max_len=max_len)
+            assert len(ids) == max_len + 1 and ids[0] == 0 and len(fin) == 2
+            if dtype == torch.float32:
+                assert ids == z[f"s{b}_a_ids"].tolist() and abs(score - float(z[f"s{b}_a_score"])) < 1e-3
+                assert np.allclose([f[0] for f in fin], z[f"s{b}_a_final_scores"], atol=1e-3)
+            sep = int(z[f"s{b}_b_sep"])
+            ids, score, fin = decoding.beam_search_ids(model, 0, sep, *(a[0] for a in args), beam_size=3, max_len=max_len)   # (sample without a batch axis)
+            assert ids[0] == 0 and 2 <= len(ids) <= max_len + 1
+            if dtype == torch.float32:
+                assert ids[-1] == sep
+                assert ids == z[f"s{b}_b_ids"].tolist() and abs(score - float(z[f"s{b}_b_score"])) < 1e-3
+                assert [len(f[1]) for f in fin] == z[f"s{b}_b_final_lens"].tolist()
+                text = decoding.beam_search(model, _StubTokenizer(sep), *args, beam_size=3, max_len=max_len, device=dev)
+                assert text == [" ".join(str(i) for i in z[f"s{b}_b_ids"].tolist()[1:-1])]
+    finally:
+        _set(torch.float32)
+
+
 @pytest.mark.parametrize("B", [3, 4])
 def test_iaog_tiny_matches_reference(dev, B):
     """IAOG pre-training step against the REFERENCE fixture: logits, loss, the gradient of every parameter (norms +

@@ -27,6 +27,11 @@ def test_star_exports_and_constants():
     assert all(hasattr(rm, n) for n in ("clones", "box_attention", "BoxMultiHeadedAttention"))
     from fcmf_framework.resnet_utils import myResNetImg, myResNetRoI  # noqa: F401
     from fcmf_framework.optimization import BertAdam, SCHEDULES, warmup_linear  # noqa: F401
+    import inspect
+    from fcmf_framework.fcmf_pretraining import beam_search        # (fcmf_pretraining.py:383-386: the reference's signature)
+    assert list(inspect.signature(beam_search).parameters) == [
+        "model", "tokenizer", "enc_ids", "enc_mask", "enc_type", "add_mask", "vis_embeds", "roi_embeds", "roi_coors",
+        "beam_size", "num_preds", "max_len", "device"]
     assert set(SCHEDULES) == {"warmup_cosine", "warmup_constant", "warmup_linear"}
 
 
