@@ -216,10 +216,11 @@ def run_fcmf(args, rank, world, dev, large=False):
     opt = FusedAdamW(param_groups(model), lr=7e-4)
     sched = get_linear_schedule_with_warmup(opt, int(0.1 * 1000), 1000)
     red = arena = None
-    if world > 1 or not args.no_arena:
+    if world > 1 or args.dp_one_rank or not args.no_arena:
         arena = GradArena.for_model(model)     # as run_multimodal_fcmf.py does (leaves out bert.cell.pooler: it never gets a gradient)
-        if world > 1:
-            red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native, group_mb=args.dp_group_mb)
+        if world > 1 or args.dp_one_rank:
+            red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native, group_mb=args.dp_group_mb,
+                              single_rank=args.dp_one_rank)
             red.broadcast_parameters(0)
     host = synth.synth_batch(B, CFG, S=S, num_imgs=NI, num_roi=NR, num_aspects=A, seed=42 + rank)
     batch = {k: v.to(dev) for k, v in host.items()}
@@ -337,8 +338,9 @@ def run_iaog(args, rank, world, dev):
                       {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}], lr=3e-5)
     arena = GradArena.for_model(model)      # one memset per step instead of a zero fill per weight gradient
     red = None
-    if world > 1:
-        red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native, group_mb=args.dp_group_mb)
+    if world > 1 or args.dp_one_rank:
+        red = GradReducer(arena, exchange=args.dp_exchange, native=args.dp_native, group_mb=args.dp_group_mb,
+                          single_rank=args.dp_one_rank)
         red.broadcast_parameters(0)
     b = synth.synth_batch(B, cfg, S=S, num_imgs=NI, num_roi=NR, num_aspects=1, seed=3 + rank, coord_dtype=torch.float32)
     b = {k: v.to(dev) for k, v in b.items()}
@@ -471,6 +473,9 @@ def main():
     ap.add_argument("--no-arena", dest="no_arena", action="store_true",
                     help="single GPU: per-weight gradient tensors instead of the flat gradient arena the drivers use (always on for --gpus > 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--dp-one-rank", action="store_true",
+                    help="rehearsal on ONE GPU: run the whole data-parallel machinery (arena, hooks, launch groups, one RCCL collective per "
+                         "bucket on the side stream, finish()) in a process group of one rank; the line carries the `dp` object")
     ap.add_argument("--dp-exchange", dest="dp_exchange", default="fp32", choices=["fp32", "bf16"],
                     help="gradient exchange: float32 all-reduce in place (default, DDP-comparable) or bf16 on the links with float32 accumulation")
     ap.add_argument("--dp-native", dest="dp_native", action="store_true",
@@ -491,12 +496,23 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     if args.launch_check:
         sys.exit(launch_check(args, rank, world))
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout when the
+    # first communicator is created -- seen in the one-rank rehearsal): from here on file descriptor 1 of this process is its stderr,
+    # and the JSON line goes to the ORIGINAL stdout kept in `json_out`.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     local = int(os.environ.get("LOCAL_RANK", 0))
     if os.environ.get("FCMF_BENCH_SINGLE_DEVICE"):   # rehearsal: several ranks share cuda:0 (use with --backend gloo)
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.dp_one_rank:
+        if world == 1:                                          # --dp-one-rank outside a launcher: a group of this process alone
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
         else:
@@ -506,11 +522,12 @@ def main():
     runner = {"fcmf": run_fcmf, "fcmf-large": lambda *a: run_fcmf(*a, large=True), "iaog": run_iaog, "resnet": run_resnet}
     out = runner[args.workload](args, rank, world, dev)
     if rank == 0:
-        if world > 1:
+        if dist.is_initialized():
             out["dp_backend"] = dist.get_backend()
             out["dp_ranks_seen"] = dist.get_world_size()
-        print(json.dumps(out))
-    if world > 1:
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

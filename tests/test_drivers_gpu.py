@@ -234,3 +234,25 @@ def test_bare_bench_gpus2_runs_the_real_step_on_two_ranks(dev):
     assert 2 <= dp["launch_groups"] < dp["buckets"], dp
     assert dp["dw_matrices_per_batched_launch"] >= 2.5, dp
     assert doc["value"] > 0 and doc["loss"] == doc["loss"]
+
+
+def test_bench_over_rccl_prints_exactly_one_json_line(dev):
+    """the data-parallel bench path over RCCL as far as one GPU allows (--dp-one-rank: process group "nccl" of one rank bound to
+    the device, arena + hooks + launch groups + one RCCL all-reduce per bucket on the side stream + finish()).  RCCL writes a
+    version banner to STDOUT when the first communicator is created; the bench contract is ONE JSON line there (what the scaling
+    driver parses), so stdout must hold that line and nothing else.  reference: run_multimodal_fcmf.py:126-131,237-240"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dp-one-rank", "--steps", "2", "--warmup", "1", "--batch", "8",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1 and out[0].startswith("{"), r.stdout[:2000]
+    doc = json.loads(out[0])
+    assert doc["n_gpus"] == 1 and doc["dp_backend"] == "nccl" and doc["dp_ranks_seen"] == 1
+    dp = doc["dp"]
+    assert dp["buckets"] >= 10 and 2 <= dp["launch_groups"] < dp["buckets"] and dp["exposed_comm_ms_per_step"] is not None
+    assert doc["value"] > 0 and doc["loss"] == doc["loss"]
