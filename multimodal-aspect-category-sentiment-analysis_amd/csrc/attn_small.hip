@@ -905,6 +905,153 @@ __global__ __launch_bounds__(256) void attn_tiny_bwd_blocked_kernel(AttnK P) {
   }
 }
 
+// =========================================================================================================================
+// "Few query rows" backward: the two fusion attentions of the step (R = 7 [CLS] rows, one per image, against <= 128 shared
+// text keys and / or each row's own private keys; bf16, no bias, no causal fill).  The general kernel gives a wave a row (7
+// rows on 4 waves: two rounds, the second three quarters full) and then a shared key (32 keys per wave one after the other,
+// 7-long dependent sums, 128-byte stores).  Nothing here needs a reduction -- the probabilities come from the saved
+// logsumexp -- so the work is flat: thread = (row, key) for probabilities / score gradients, thread = (row, 8 columns,
+// quarter of the keys) for dq, thread = (shared key, 8 columns) for dk1 / dv1 with 16-byte stores.  Same dropout counters;
+// the private keys of grouped sequences leave through the pd2 / ds2 scratch exactly as in the general kernel.
+// =========================================================================================================================
+__device__ __forceinline__ float dot_bf16_lds_gl(const bf16_t* a_lds, const bf16_t* __restrict__ b_gl, int d) {   // d % 8 == 0
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  float s0 = 0.f, s1 = 0.f;
+  for (int c = 0; c < d; c += 8) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(a_lds + c), y = *reinterpret_cast<const bf16x8*>(b_gl + c);
+    s0 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{x[0], x[1]}, bf16x2_t{y[0], y[1]}, s0, false);
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{x[2], x[3]}, bf16x2_t{y[2], y[3]}, s1, false);
+    s0 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{x[4], x[5]}, bf16x2_t{y[4], y[5]}, s0, false);
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{x[6], x[7]}, bf16x2_t{y[6], y[7]}, s1, false);
+  }
+  return s0 + s1;
+}
+
+__global__ __launch_bounds__(256) void attn_rows_flat_bwd_kernel(AttnK P) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const fcmf_attn_desc& a = P.a;
+  const int d = a.d, T1 = a.T1, T2 = a.T2, T = T1 + T2, R = a.R, dp = d + 8, TP = T + 1, d8 = d >> 3;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(sm);            // [R][dp]
+  bf16_t* dOs = Qs + R * dp;                             // [R][dp]
+  bf16_t* Ks = dOs + R * dp;                             // [T1][dp]
+  bf16_t* Vs = Ks + T1 * dp;                             // [T1][dp]
+  float* PD = reinterpret_cast<float*>(Vs + T1 * dp);    // [R][TP] dropped probabilities
+  float* DS = PD + R * TP;                               // [R][TP] score gradients
+  float* dl = DS + R * TP;                               // [R] delta = <dO, O>
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = blockIdx.x / a.heads, h = blockIdx.x % a.heads, g2 = g / a.group_div;
+  const int64_t HD = (int64_t)a.heads * d;
+  const bf16_t* dO = reinterpret_cast<const bf16_t*>(P.dout);
+  const bf16_t* O = reinterpret_cast<const bf16_t*>(P.o_in);
+  const bf16_t* K2 = reinterpret_cast<const bf16_t*>(a.k2);
+  const bf16_t* V2 = reinterpret_cast<const bf16_t*>(a.v2);
+  stage_rows<bf16_t, bf16_t>(Qs, dp, reinterpret_cast<const bf16_t*>(a.q) + (int64_t)g * a.q_sg + h * d, a.q_sr, R, d, w, lane);
+  stage_rows<bf16_t, bf16_t>(dOs, dp, dO + (int64_t)g * a.o_sg + h * d, a.o_sr, R, d, w, lane);
+  if (T1 > 0) {
+    stage_rows<bf16_t, bf16_t>(Ks, dp, reinterpret_cast<const bf16_t*>(a.k1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T1, d, w, lane);
+    stage_rows<bf16_t, bf16_t>(Vs, dp, reinterpret_cast<const bf16_t*>(a.v1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T1, d, w, lane);
+  }
+  for (int idx = tid; idx < R * T; idx += 256) {         // score offsets: + mask - logsumexp (+inf: fully hard-masked row)
+    const int r = idx / T, t = idx - r * T;
+    const float add = a.mask ? a.mask[(int64_t)g * T + t] : 0.f;
+    const float lse_r = P.lse[((int64_t)g * a.heads + h) * R + r];
+    DS[r * TP + t] = lse_r <= -1e30f ? INFINITY : add - lse_r;
+  }
+  for (int r = w; r < R; r += 4) {
+    const bf16_t* orow = O + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
+    const bf16_t* drow = dO + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d;
+    float part = 0.f;
+    for (int c = lane; c < d; c += 64) part += (float)drow[c] * (float)orow[c];
+    part = wave_sum(part);
+    if (lane == 0) dl[r] = part;
+  }
+  __syncthreads();
+  const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  for (int idx = tid; idx < R * T; idx += 256) {         // thread = (row, key)
+    const int r = idx / T, t = idx - r * T;
+    float s, dpd;
+    if (t < T1) {
+      s = dot_bf16_lds(Qs + r * dp, Ks + t * dp, d);
+      dpd = dot_bf16_lds(dOs + r * dp, Vs + t * dp, d);
+    } else {                                             // private key: its K2 / V2 rows straight from global memory
+      const int64_t o2 = (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + (int64_t)(t - T1) * a.k2_st + h * d;
+      s = dot_bf16_lds_gl(Qs + r * dp, K2 + o2, d);
+      dpd = dot_bf16_lds_gl(dOs + r * dp, V2 + o2, d);
+    }
+    const float off = DS[r * TP + t];                    // (staged by this same thread)
+    const float pr = off == INFINITY ? 1.0f / (float)T : __expf(s * a.scale + off);
+    float mult = 1.0f;
+    if (a.dropout_p > 0.f) mult = dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + t, a.dropout_p, inv_keep);
+    const float dsv = pr * (dpd * mult - dl[r]);
+    PD[r * TP + t] = pr * mult;
+    DS[r * TP + t] = dsv;
+    if (t >= T1 && P.pd2) {
+      const int64_t i2 = (((int64_t)g * a.heads + h) * R + r) * T2 + (t - T1);
+      P.pd2[i2] = pr * mult;
+      P.ds2[i2] = dsv;
+    }
+  }
+  __syncthreads();
+  // dq[r][c] = scale * sum_t ds[r][t] k[t][c]: thread = (row, 8 columns, quarter of the keys), the four quarters in
+  // neighbouring lanes and summed across them
+  bf16_t* dQ = reinterpret_cast<bf16_t*>(P.dq);
+  for (int item = tid >> 2; item < R * d8; item += 64) {
+    const int r = item / d8, c = (item - r * d8) * 8, qt = tid & 3;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = qt; t < T1; t += 4) {
+      const float dsv = DS[r * TP + t];
+      const bf16x8 kk = *reinterpret_cast<const bf16x8*>(Ks + t * dp + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += dsv * (float)kk[j];
+    }
+    const int64_t p2 = (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + h * d + c;
+    for (int t2 = qt; t2 < T2; t2 += 4) {
+      const float dsv = DS[r * TP + T1 + t2];
+      const bf16x8 kk = *reinterpret_cast<const bf16x8*>(K2 + p2 + (int64_t)t2 * a.k2_st);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += dsv * (float)kk[j];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[j];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      o[j] = (bf16_t)(v * a.scale);
+    }
+    if (qt == 0) *reinterpret_cast<bf16x8*>(dQ + ((int64_t)g * R + r) * HD + h * d + c) = o;
+  }
+  // dk1 / dv1 [t][c] = sum_r ds / pd [r][t] * q / dO [r][c]: thread = (shared key, 8 columns)
+  bf16_t* dK = reinterpret_cast<bf16_t*>(P.dk1);
+  bf16_t* dV = reinterpret_cast<bf16_t*>(P.dv1);
+  for (int idx = tid; idx < T1 * d8; idx += 256) {
+    const int t = idx / d8, c = (idx - t * d8) * 8;
+    float k[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r) {
+      const float dsv = DS[r * TP + t], pv = PD[r * TP + t];
+      const bf16x8 qq = *reinterpret_cast<const bf16x8*>(Qs + r * dp + c), gg = *reinterpret_cast<const bf16x8*>(dOs + r * dp + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { k[j] += dsv * (float)qq[j]; v[j] += pv * (float)gg[j]; }
+    }
+    bf16x8 ok, ov;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ok[j] = (bf16_t)(k[j] * a.scale); ov[j] = (bf16_t)v[j]; }
+    *reinterpret_cast<bf16x8*>(dK + ((int64_t)g * T1 + t) * HD + h * d + c) = ok;
+    *reinterpret_cast<bf16x8*>(dV + ((int64_t)g * T1 + t) * HD + h * d + c) = ov;
+  }
+}
+
+// the flat few-rows backward's preconditions (host)
+static bool rows_flat_ok(const fcmf_attn_desc* a) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!(a->dtype == FCMF_BF16 && !a->causal && !a->head_quirk && !a->bias && a->R <= 16 && a->T1 <= 128 && a->d % 8 == 0 &&
+        a->q_sr % 8 == 0 && a->q_sg % 8 == 0 && a->o_sr % 8 == 0 && a->o_sg % 8 == 0 && al16(a->q)))
+    return false;
+  if (a->T1 > 0 && !(a->k1_st % 8 == 0 && a->k1_sg % 8 == 0 && al16(a->k1) && al16(a->v1))) return false;
+  if (a->T2 > 0 && !(a->k2_sg % 8 == 0 && a->k2_sr % 8 == 0 && a->k2_st % 8 == 0 && al16(a->k2) && al16(a->v2))) return false;
+  return true;
+}
+
 // the tiny kernels' preconditions (host)
 static bool tiny_ok(const fcmf_attn_desc* a) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -1023,6 +1170,25 @@ static int attn_small_bwd_impl(const fcmf_attn_desc* desc, const void* out, cons
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_tiny_bwd_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       hipLaunchKernelGGL(attn_tiny_bwd_blocked_kernel, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
       FCMF_CHECK_LAUNCH();
+      return FCMF_OK;
+    }
+  }
+  if (rows_flat_ok(desc) && !dbias && (desc->T2 == 0 || grouped) && (desc->T1 == 0 || dv1) &&
+      ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) |
+        reinterpret_cast<uintptr_t>(dk1) | reinterpret_cast<uintptr_t>(dv1)) & 15) == 0) {
+    const int dp = desc->d + 8, TP = desc->T1 + desc->T2 + 1;
+    const size_t smem = (size_t)(2 * desc->R + 2 * desc->T1) * dp * 2 + sizeof(float) * ((size_t)2 * desc->R * TP + desc->R);
+    if (smem <= 64 * 1024) {
+      hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+      hipLaunchKernelGGL(attn_rows_flat_bwd_kernel, dim3(desc->G * desc->heads), dim3(256), smem, st, P);
+      FCMF_CHECK_LAUNCH();
+      if (grouped) {
+        dim3 grid2((desc->G / desc->group_div) * desc->R, 4);
+        auto k = attn_private_grad_kernel<bf16_t>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+        hipLaunchKernelGGL(k, grid2, dim3(256), smem2, st, P);
+        FCMF_CHECK_LAUNCH();
+      }
       return FCMF_OK;
     }
   }
