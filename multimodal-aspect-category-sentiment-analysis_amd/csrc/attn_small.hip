@@ -635,6 +635,20 @@ __device__ __forceinline__ float dot_bf16_lds(const bf16_t* a, const bf16_t* b, 
   return s0 + s1;
 }
 
+// one 16 x 16 fragment of X Y^T out of two row-major LDS images (rows of d bf16, pitch dp, d % 32 == 0) on the matrix cores:
+// v_mfma_f32_16x16x32_bf16 wants 8 consecutive k per lane for row (lane & 15) of either operand at k offset 8 (lane >> 4) --
+// the same 16-byte read for both (pitch 2 (d + 8) bytes: the 16 rows of a quarter wave start in distinct bank groups).  The lane
+// ends up with rows x0 + 4 (lane >> 4) + i, i = 0..3, of column y0 + (lane & 15).  Rows past the end of an operand read whatever
+// follows it inside the workgroup's LDS allocation and only reach outputs that are never stored.
+__device__ __forceinline__ f32x4 frag_xyT(const bf16_t* X, const bf16_t* Y, int dp, int d, int x0, int y0, int lane) {
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16_t* xr = X + (x0 + (lane & 15)) * dp + (lane >> 4) * 8;
+  const bf16_t* yr = Y + (y0 + (lane & 15)) * dp + (lane >> 4) * 8;
+  for (int k0 = 0; k0 < d; k0 += 32)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xr + k0), *reinterpret_cast<const bf16x8*>(yr + k0), acc, 0, 0, 0);
+  return acc;
+}
+
 template <bool WIDE>      // WIDE: 65..128 keys, two per lane in the softmax
 __global__ __launch_bounds__(256) void attn_tiny_fwd_kernel(AttnK P) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -659,9 +673,23 @@ __global__ __launch_bounds__(256) void attn_tiny_fwd_kernel(AttnK P) {
     Ss[r * TP + t] = add;
   }
   __syncthreads();
-  for (int idx = tid; idx < R * T; idx += 256) {
-    const int r = idx / T, t = idx - r * T;
-    Ss[r * TP + t] += dot_bf16_lds(Qs + r * dp, Ks + t * dp, d) * a.scale;      // (the same thread staged this element)
+  if ((d & 31) == 0) {                                   // scores on the matrix cores: wave = 16 x 16 fragments w, w + 4, ...
+    const int nfc = (T + 15) >> 4, nf = ((R + 15) >> 4) * nfc;
+    for (int f = w; f < nf; f += 4) {
+      const int r0 = (f / nfc) * 16, t0 = (f % nfc) * 16;
+      const f32x4 acc = frag_xyT(Qs, Ks, dp, d, r0, t0, lane);
+      const int t = t0 + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * (lane >> 4) + i;
+        if (r < R && t < T) Ss[r * TP + t] += acc[i] * a.scale;
+      }
+    }
+  } else {
+    for (int idx = tid; idx < R * T; idx += 256) {
+      const int r = idx / T, t = idx - r * T;
+      Ss[r * TP + t] += dot_bf16_lds(Qs + r * dp, Ks + t * dp, d) * a.scale;
+    }
   }
   __syncthreads();
   const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
@@ -744,18 +772,33 @@ __global__ __launch_bounds__(256) void attn_tiny_bwd_kernel(AttnK P) {
   }
   __syncthreads();
   const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
-  for (int idx = tid; idx < R * T; idx += 256) {
-    const int r = idx / T, t = idx - r * T;
-    const float s = dot_bf16_lds(Qs + r * dp, Ks + t * dp, d) * a.scale;
-    const float dpd = dot_bf16_lds(dOs + r * dp, Vs + t * dp, d);
-    const float off = DS[r * TP + t];                     // (staged by this same thread: + mask + bias - logsumexp)
-    const float pr = off == INFINITY ? 1.0f / (float)T : __expf(s + off);
+  auto element = [&](int r, int t, float s, float dpd) {  // probability and score gradient of (row r, key t) from q.k and dO.v
+    const float off = DS[r * TP + t];                     // (staged above: + mask + bias - logsumexp)
+    const float pr = off == INFINITY ? 1.0f / (float)T : __expf(s * a.scale + off);
     float mult = 1.0f;
     if (a.dropout_p > 0.f) mult = dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + t, a.dropout_p, inv_keep);
     const float dsv = pr * (dpd * mult - dl[r]);
     PD[r * TP + t] = pr * mult;
     DS[r * TP + t] = dsv;
     if (P.dbias) P.dbias[(((int64_t)g * a.heads + h) * R + r) * T + t] = dsv;
+  };
+  if ((d & 31) == 0) {                                   // Q K^T and dO V^T on the matrix cores (see frag_xyT)
+    const int nfc = (T + 15) >> 4, nf = ((R + 15) >> 4) * nfc;
+    for (int f = w; f < nf; f += 4) {
+      const int r0 = (f / nfc) * 16, t0 = (f % nfc) * 16;
+      const f32x4 sv = frag_xyT(Qs, Ks, dp, d, r0, t0, lane), dv = frag_xyT(dOs, Vs, dp, d, r0, t0, lane);
+      const int t = t0 + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * (lane >> 4) + i;
+        if (r < R && t < T) element(r, t, sv[i], dv[i]);
+      }
+    }
+  } else {
+    for (int idx = tid; idx < R * T; idx += 256) {
+      const int r = idx / T, t = idx - r * T;
+      element(r, t, dot_bf16_lds(Qs + r * dp, Ks + t * dp, d), dot_bf16_lds(dOs + r * dp, Vs + t * dp, d));
+    }
   }
   __syncthreads();
   bf16_t* dQ = reinterpret_cast<bf16_t*>(P.dq);
@@ -848,18 +891,35 @@ __global__ __launch_bounds__(256) void attn_tiny_bwd_blocked_kernel(AttnK P) {
       const float lse_r = P.lse[((int64_t)g * a.heads + h) * R + r];
       DS[rl * TP + t] = lse_r <= -1e30f ? INFINITY : add - lse_r;      // (+inf: fully masked row, see the one-block kernel)
     }
-    for (int idx = tid; idx < rb * T; idx += 256) {      // (same thread per element as the staging loop: no barrier)
-      const int rl = idx / T, t = idx - rl * T, r = r0 + rl;
-      const float s = dot_bf16_lds(Qs + r * dp, Ks + t * dp, d) * a.scale;
-      const float dpd = dot_bf16_lds(dOs + r * dp, Vs + t * dp, d);
+    auto element = [&](int rl, int t, float s, float dpd) {
+      const int r = r0 + rl;
       const float off = DS[rl * TP + t];
-      const float pr = off == INFINITY ? 1.0f / (float)T : __expf(s + off);
+      const float pr = off == INFINITY ? 1.0f / (float)T : __expf(s * a.scale + off);
       float mult = 1.0f;
       if (a.dropout_p > 0.f) mult = dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + t, a.dropout_p, inv_keep);
       const float dsv = pr * (dpd * mult - dl[r]);
       PD[rl * TP + t] = pr * mult;
       DS[rl * TP + t] = dsv;
       if (P.dbias) P.dbias[(((int64_t)g * a.heads + h) * R + r) * T + t] = dsv;
+    };
+    if ((d & 31) == 0) {                                 // Q K^T and dO V^T of the row block on the matrix cores (see frag_xyT)
+      __syncthreads();                                   // (another thread staged the element's offset)
+      const int nfc = (T + 15) >> 4, nf = ((rb + 15) >> 4) * nfc;
+      for (int f = w; f < nf; f += 4) {
+        const int rl0 = (f / nfc) * 16, t0 = (f % nfc) * 16;
+        const f32x4 sv = frag_xyT(Qs, Ks, dp, d, r0 + rl0, t0, lane), dv = frag_xyT(dOs, Vs, dp, d, r0 + rl0, t0, lane);
+        const int t = t0 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rl = rl0 + 4 * (lane >> 4) + i;
+          if (rl < rb && t < T) element(rl, t, sv[i], dv[i]);
+        }
+      }
+    } else {
+      for (int idx = tid; idx < rb * T; idx += 256) {    // (same thread per element as the staging loop: no barrier)
+        const int rl = idx / T, t = idx - rl * T;
+        element(rl, t, dot_bf16_lds(Qs + (r0 + rl) * dp, Ks + t * dp, d), dot_bf16_lds(dOs + (r0 + rl) * dp, Vs + t * dp, d));
+      }
     }
     __syncthreads();
     for (int idx = tid; idx < rb * d8; idx += 256) {     // dQ rows of the block: thread = (row, 8 columns)
@@ -1090,7 +1150,10 @@ extern "C" int fcmf_attn_small_fwd(const fcmf_attn_desc* desc, void* out, float*
   P.a = *desc; P.out = out; P.lse = lse;
   if (tiny_ok(desc) && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     const int dp = desc->d + 8;
-    const size_t smem = (size_t)(desc->R + 2 * desc->T1) * dp * 2 + sizeof(float) * (size_t)desc->R * (desc->T1 + 1);
+    // (the matrix-core score fragments read up to 15 rows past the end of the K image: into V and the score array, or the pad)
+    size_t smem = (size_t)(desc->R + 2 * desc->T1) * dp * 2 + sizeof(float) * (size_t)desc->R * (desc->T1 + 1);
+    const size_t after_k = (size_t)desc->T1 * dp * 2 + sizeof(float) * (size_t)desc->R * (desc->T1 + 1), over = (size_t)15 * dp * 2;
+    if (after_k < over) smem += over - after_k;
     if (smem <= TINY_LDS) {
       auto k = desc->T1 > 64 ? attn_tiny_fwd_kernel<true> : attn_tiny_fwd_kernel<false>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1153,7 +1216,11 @@ static int attn_small_bwd_impl(const fcmf_attn_desc* desc, const void* out, cons
       ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) |
         reinterpret_cast<uintptr_t>(dk1) | reinterpret_cast<uintptr_t>(dv1)) & 15) == 0) {
     const int dp = desc->d + 8;
-    const size_t opnd = (size_t)(2 * desc->R + 2 * desc->T1) * dp * 2 + sizeof(float) * (size_t)desc->R;
+    size_t opnd = (size_t)(2 * desc->R + 2 * desc->T1) * dp * 2 + sizeof(float) * (size_t)desc->R;
+    {   // the score fragments read up to 15 rows past the end of the V image: into the f32 arrays behind it, or a pad
+      const size_t tail = sizeof(float) * ((size_t)2 * (desc->R < 16 ? desc->R : 16) * (desc->T1 + 1) + desc->R), over = (size_t)15 * dp * 2;
+      if (tail < over) opnd += over - tail;
+    }
     const size_t row = sizeof(float) * 2 * (size_t)(desc->T1 + 1);      // one row of the two [rows][T + 1] f32 arrays
     if (desc->R <= TINY_MAX && desc->T1 <= TINY_MAX && opnd + desc->R * row <= TINY_LDS) {
       const size_t smem = opnd + desc->R * row;
