@@ -1101,6 +1101,96 @@ __global__ __launch_bounds__(256) void attn_rows_flat_bwd_kernel(AttnK P) {
   }
 }
 
+// the forward of the same geometry, flat as well: thread = (row, key) scores, wave = row softmax (a few elements per lane),
+// thread = (row, 8 columns, quarter of the keys) outputs
+__global__ __launch_bounds__(256) void attn_rows_flat_fwd_kernel(AttnK P) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const fcmf_attn_desc& a = P.a;
+  const int d = a.d, T1 = a.T1, T2 = a.T2, T = T1 + T2, R = a.R, dp = d + 8, TP = T + 1, d8 = d >> 3;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(sm);            // [R][dp]
+  bf16_t* Ks = Qs + R * dp;                              // [T1][dp]
+  bf16_t* Vs = Ks + T1 * dp;                             // [T1][dp]
+  float* Ss = reinterpret_cast<float*>(Vs + T1 * dp);    // [R][TP] scores, then dropped probabilities
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = blockIdx.x / a.heads, h = blockIdx.x % a.heads, g2 = g / a.group_div;
+  const bf16_t* K2 = reinterpret_cast<const bf16_t*>(a.k2);
+  const bf16_t* V2 = reinterpret_cast<const bf16_t*>(a.v2);
+  stage_rows<bf16_t, bf16_t>(Qs, dp, reinterpret_cast<const bf16_t*>(a.q) + (int64_t)g * a.q_sg + h * d, a.q_sr, R, d, w, lane);
+  if (T1 > 0) {
+    stage_rows<bf16_t, bf16_t>(Ks, dp, reinterpret_cast<const bf16_t*>(a.k1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T1, d, w, lane);
+    stage_rows<bf16_t, bf16_t>(Vs, dp, reinterpret_cast<const bf16_t*>(a.v1) + (int64_t)g * a.k1_sg + h * d, a.k1_st, T1, d, w, lane);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < R * T; idx += 256) {         // thread = (row, key)
+    const int r = idx / T, t = idx - r * T;
+    float s;
+    if (t < T1) s = dot_bf16_lds(Qs + r * dp, Ks + t * dp, d);
+    else s = dot_bf16_lds_gl(Qs + r * dp, K2 + (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + (int64_t)(t - T1) * a.k2_st + h * d, d);
+    s *= a.scale;
+    if (a.mask) s += a.mask[(int64_t)g * T + t];
+    Ss[r * TP + t] = s;
+  }
+  __syncthreads();
+  const float inv_keep = a.dropout_p > 0.f ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  for (int r = w; r < R; r += 4) {                       // wave = row: T <= 384 keys, up to 6 per lane
+    float sv[6], m = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int t = lane + 64 * n;
+      sv[n] = t < T ? Ss[r * TP + t] : -INFINITY;
+      m = fmaxf(m, sv[n]);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int t = lane + 64 * n;
+      sv[n] = t < T ? __expf(sv[n] - m) : 0.f;
+      sum += sv[n];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int t = lane + 64 * n;
+      if (t < T) {
+        float pv = sv[n] * inv;
+        if (a.dropout_p > 0.f) pv *= dropout_mult(a.seed, (((uint64_t)g * a.heads + h) * R + r) * T + t, a.dropout_p, inv_keep);
+        Ss[r * TP + t] = pv;
+      }
+    }
+    if (lane == 0 && P.lse) P.lse[((int64_t)g * a.heads + h) * R + r] = m + __logf(sum);
+  }
+  __syncthreads();
+  bf16_t* O = reinterpret_cast<bf16_t*>(P.out);
+  for (int item = tid >> 2; item < R * d8; item += 64) {  // thread = (row, 8 columns, quarter of the keys)
+    const int r = item / d8, c = (item - r * d8) * 8, qt = tid & 3;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = qt; t < T1; t += 4) {
+      const float pv = Ss[r * TP + t];
+      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(Vs + t * dp + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += pv * (float)vv[j];
+    }
+    const int64_t p2 = (int64_t)g2 * a.k2_sg + (int64_t)r * a.k2_sr + h * d + c;
+    for (int t2 = qt; t2 < T2; t2 += 4) {
+      const float pv = Ss[r * TP + T1 + t2];
+      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(V2 + p2 + (int64_t)t2 * a.k2_st);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += pv * (float)vv[j];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[j];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      o[j] = (bf16_t)v;
+    }
+    if (qt == 0) *reinterpret_cast<bf16x8*>(O + (int64_t)g * a.o_sg + (int64_t)r * a.o_sr + h * d + c) = o;
+  }
+}
+
 // the flat few-rows backward's preconditions (host)
 static bool rows_flat_ok(const fcmf_attn_desc* a) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -1158,6 +1248,15 @@ extern "C" int fcmf_attn_small_fwd(const fcmf_attn_desc* desc, void* out, float*
       auto k = desc->T1 > 64 ? attn_tiny_fwd_kernel<true> : attn_tiny_fwd_kernel<false>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       hipLaunchKernelGGL(k, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
+      FCMF_CHECK_LAUNCH();
+      return FCMF_OK;
+    }
+  }
+  if (rows_flat_ok(desc) && desc->T1 + desc->T2 <= 384 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int dp = desc->d + 8, TP = desc->T1 + desc->T2 + 1;
+    const size_t smem = (size_t)(desc->R + 2 * desc->T1) * dp * 2 + sizeof(float) * (size_t)desc->R * TP;
+    if (smem <= 64 * 1024) {
+      hipLaunchKernelGGL(attn_rows_flat_fwd_kernel, dim3(desc->G * desc->heads), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), P);
       FCMF_CHECK_LAUNCH();
       return FCMF_OK;
     }
