@@ -232,7 +232,10 @@ int fcmf_embed_pos_bwd(const void* dz, const int64_t* pos, float* dpos, int nseq
  *   bias[g,h,i,j] = log(max(relu(<WG_h, emb(box_i, box_j)> + b_h), 1e-6))
  * coords [G,N,4] = (x_min,x_max,y_min,y_max) in float64 or float32 (coord_dtype);
  * wg_w [heads,64], wg_b [heads] float32 (heads <= 8); bias float32 [G,heads,N,N];
- * dim_mat: device float32[8] = 1/1000^(k/8) as the reference rounds it (roi_modeling.py:123-125). */
+ * dim_mat: device float32[8] = 1/1000^(k/8) as the reference rounds it (roi_modeling.py:123-125).
+ * coord_dtype = FCMF_F32 | FCMF_BOX_FAST_TRIG: the 64 sines / cosines of a box pair on the hardware's v_sin_f32 / v_cos_f32
+ * (arguments up to ~110 revolutions: absolute error <= 1e-4, against 1e-7 of sincosf) -- for a bias that is consumed in bf16. */
+#define FCMF_BOX_FAST_TRIG 0x100
 int fcmf_box_bias_fwd(const void* coords, int coord_dtype, const float* dim_mat, const float* wg_w,
                       const float* wg_b, float* bias, int G, int N, int heads, void* stream);
 /* dwg_w/dwg_b are ACCUMULATED. */

@@ -20,7 +20,8 @@ template <> struct Trig<float> {
 };
 
 // emb[0..31] = sin(100 * delta_c * dim_mat[k]), emb[32..63] = cos(...), index c*8+k (:128-135)
-template <typename CT>
+// FAST (float coordinates only, FCMF_BOX_FAST_TRIG): the hardware's v_sin_f32 / v_cos_f32 (input in revolutions) instead of sincosf
+template <typename CT, bool FAST = false>
 __device__ __forceinline__ void box_embed(const CT* __restrict__ coords, const float* __restrict__ dim_mat, int64_t g,
                                           int N, int i, int j, float (&emb)[64]) {
   const CT* bi = coords + (g * N + i) * 4;
@@ -40,14 +41,20 @@ __device__ __forceinline__ void box_embed(const CT* __restrict__ coords, const f
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       CT s, co;
-      Trig<CT>::sc(base * (CT)dim_mat[k], &s, &co);
+      if constexpr (FAST) {
+        const float rev = (float)(base * (CT)dim_mat[k]) * 0.15915494309189535f;
+        s = __builtin_amdgcn_sinf(rev);
+        co = __builtin_amdgcn_cosf(rev);
+      } else {
+        Trig<CT>::sc(base * (CT)dim_mat[k], &s, &co);
+      }
       emb[c * 8 + k] = (float)s;
       emb[32 + c * 8 + k] = (float)co;
     }
   }
 }
 
-template <typename CT>
+template <typename CT, bool FAST = false>
 __global__ __launch_bounds__(256) void box_bias_fwd_kernel(const CT* __restrict__ coords, const float* __restrict__ dim_mat,
                                                            const float* __restrict__ wg_w, const float* __restrict__ wg_b,
                                                            float* __restrict__ bias, float* __restrict__ emb_out,
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(256) void box_bias_fwd_kernel(const CT* __restrict_
     const int rem = (int)(idx - g * N * N);
     const int i = rem / N, j = rem - i * N;
     float emb[64];
-    box_embed<CT>(coords, dim_mat, g, N, i, j, emb);
+    box_embed<CT, FAST>(coords, dim_mat, g, N, i, j, emb);
     if (emb_out) {
 #pragma unroll
       for (int e = 0; e < 64; ++e) emb_out[idx * 64 + e] = emb[e];
@@ -80,60 +87,78 @@ __global__ __launch_bounds__(256) void box_bias_fwd_kernel(const CT* __restrict_
   }
 }
 
-template <typename CT>
+template <typename CT, bool FAST = false>
 __global__ __launch_bounds__(256) void box_bias_bwd_kernel(const CT* __restrict__ coords, const float* __restrict__ dim_mat,
                                                            const float* __restrict__ wg_w, const float* __restrict__ wg_b,
                                                            const float* __restrict__ dbias, float* __restrict__ dwg_w,
                                                            float* __restrict__ dwg_b, int G, int N, int heads) {
-  // per iteration the block stages 256 embeddings E[256][65] and pre-activation grads D[256][8];
-  // each thread then owns two (head, e) entries of the 8x64 (+bias column) outer-product sum.
+  // per iteration the block stages 256 embeddings E[256][65] and pre-activation gradients D[256][8]; then lane e of wave v adds
+  // the rows r = v, v + 4, ... into ITS partial sums of column e for all 8 heads (one E read and two broadcast 16-byte D reads per
+  // 8 FMAs: the round-3 form -- two (head, e) outputs per thread over all 256 rows -- spent three LDS reads on every two FMAs and
+  // two thirds of the kernel's time in that loop).  The four waves' partial sums meet in LDS once, after the last iteration.
   __shared__ float w[8 * 64 + 8];
   __shared__ float E[256][65];
-  __shared__ float D[256][9];
+  __shared__ __attribute__((aligned(16))) float D[256][8];
   for (int e = threadIdx.x; e < heads * 64 + heads; e += 256) w[e] = e < heads * 64 ? wg_w[e] : wg_b[e - heads * 64];
   __syncthreads();
   const int64_t total = (int64_t)G * N * N;
-  const int tid = threadIdx.x;
-  // outputs owned: o0 = tid, o1 = tid + 256 over the heads*64 weight entries; thread < heads also owns db[tid]
-  float a0 = 0.f, a1 = 0.f, ab = 0.f;
-  const int h0 = tid >> 6, e0 = tid & 63, h1 = (tid + 256) >> 6, e1 = e0;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // d WG[h][lane] over this wave's rows
+  float ab[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // d b[h] over this wave's rows (lane-strided, summed at the end)
   for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {
     const int64_t idx = base + tid;
+    float dh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (idx < total) {
       const int64_t g = idx / (N * N);
       const int rem = (int)(idx - g * N * N);
       const int i = rem / N, j = rem - i * N;
       float emb[64];
-      box_embed<CT>(coords, dim_mat, g, N, i, j, emb);
+      box_embed<CT, FAST>(coords, dim_mat, g, N, i, j, emb);
 #pragma unroll
       for (int e = 0; e < 64; ++e) E[tid][e] = emb[e];
       for (int h = 0; h < heads; ++h) {
-        float acc = 0.f;
+        float a = 0.f;
 #pragma unroll
-        for (int e = 0; e < 64; ++e) acc += emb[e] * w[h * 64 + e];
-        acc += w[heads * 64 + h];
+        for (int e = 0; e < 64; ++e) a += emb[e] * w[h * 64 + e];
+        a += w[heads * 64 + h];
         const float db = dbias[((g * heads + h) * N + i) * N + j];
         // d log(max(relu(x),1e-6)) / dx = 1/x where x > 1e-6, else 0
-        D[tid][h] = acc > 1e-6f ? db / acc : 0.f;
+        dh[h] = a > 1e-6f ? db / a : 0.f;
       }
     } else {
 #pragma unroll
       for (int e = 0; e < 64; ++e) E[tid][e] = 0.f;
-      for (int h = 0; h < heads; ++h) D[tid][h] = 0.f;
     }
+    *reinterpret_cast<float4*>(&D[tid][0]) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+    *reinterpret_cast<float4*>(&D[tid][4]) = make_float4(dh[4], dh[5], dh[6], dh[7]);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) ab[h] += dh[h];
     __syncthreads();
-    for (int r = 0; r < 256; ++r) {
-      const float er = E[r][e0];
-      if (h0 < heads) a0 += D[r][h0] * er;
-      if (h1 < heads) a1 += D[r][h1] * er;
+#pragma unroll 4
+    for (int r = wv; r < 256; r += 4) {
+      const float er = E[r][lane];
+      const float4 d0 = *reinterpret_cast<const float4*>(&D[r][0]), d1 = *reinterpret_cast<const float4*>(&D[r][4]);
+      acc[0] += d0.x * er; acc[1] += d0.y * er; acc[2] += d0.z * er; acc[3] += d0.w * er;
+      acc[4] += d1.x * er; acc[5] += d1.y * er; acc[6] += d1.z * er; acc[7] += d1.w * er;
     }
-    if (tid < heads)
-      for (int r = 0; r < 256; ++r) ab += D[r][tid];
     __syncthreads();
   }
-  if (h0 < heads) atomicAdd(dwg_w + h0 * 64 + e0, a0);
-  if (h1 < heads) atomicAdd(dwg_w + h1 * 64 + e1, a1);
-  if (tid < heads) atomicAdd(dwg_b + tid, ab);
+  // cross-wave sums through LDS (E is free now): P[wave][h][e], then one atomic per output and block
+  float* Pw = &E[0][0];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) Pw[(wv * 8 + h) * 64 + lane] = acc[h];
+  float* Pb = Pw + 4 * 8 * 64;                           // [wave][h]
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const float sgm = wave_sum(ab[h]);
+    if (lane == 0) Pb[wv * 8 + h] = sgm;
+  }
+  __syncthreads();
+  for (int o = tid; o < heads * 64; o += 256) {
+    const int h = o >> 6, e = o & 63;
+    atomicAdd(dwg_w + o, Pw[(0 * 8 + h) * 64 + e] + Pw[(1 * 8 + h) * 64 + e] + Pw[(2 * 8 + h) * 64 + e] + Pw[(3 * 8 + h) * 64 + e]);
+  }
+  if (tid < heads) atomicAdd(dwg_b + tid, Pb[tid] + Pb[8 + tid] + Pb[16 + tid] + Pb[24 + tid]);
 }
 
 static int box_grid(int64_t total) {
@@ -150,6 +175,8 @@ extern "C" int fcmf_box_bias_fwd(const void* coords, int coord_dtype, const floa
     hipLaunchKernelGGL((box_bias_fwd_kernel<double>), grid, dim3(256), 0, st, (const double*)coords, dim_mat, wg_w, wg_b, bias, (float*)nullptr, G, N, heads);
   else if (coord_dtype == FCMF_F32)
     hipLaunchKernelGGL((box_bias_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)coords, dim_mat, wg_w, wg_b, bias, (float*)nullptr, G, N, heads);
+  else if (coord_dtype == (FCMF_F32 | FCMF_BOX_FAST_TRIG))
+    hipLaunchKernelGGL((box_bias_fwd_kernel<float, true>), grid, dim3(256), 0, st, (const float*)coords, dim_mat, wg_w, wg_b, bias, (float*)nullptr, G, N, heads);
   else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;
@@ -181,6 +208,8 @@ extern "C" int fcmf_box_bias_bwd(const void* coords, int coord_dtype, const floa
     hipLaunchKernelGGL((box_bias_bwd_kernel<double>), grid, dim3(256), 0, st, (const double*)coords, dim_mat, wg_w, wg_b, dbias, dwg_w, dwg_b, G, N, heads);
   else if (coord_dtype == FCMF_F32)
     hipLaunchKernelGGL((box_bias_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)coords, dim_mat, wg_w, wg_b, dbias, dwg_w, dwg_b, G, N, heads);
+  else if (coord_dtype == (FCMF_F32 | FCMF_BOX_FAST_TRIG))
+    hipLaunchKernelGGL((box_bias_bwd_kernel<float, true>), grid, dim3(256), 0, st, (const float*)coords, dim_mat, wg_w, wg_b, dbias, dwg_w, dwg_b, G, N, heads);
   else return FCMF_ERR_UNSUPPORTED;
   FCMF_CHECK_LAUNCH();
   return FCMF_OK;

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfcmf_hip.so")
 
 F32, BF16, F64 = 0, 1, 2
+BOX_FAST_TRIG = 0x100      # OR-ed into fcmf_box_bias_*'s coord_dtype (include/fcmf_hip.h FCMF_BOX_FAST_TRIG)
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_DGELU, EPI_DTANH, EPI_ADD = 0, 1, 2, 3, 4, 5
 ERR_UNSUPPORTED = -3      # FCMF_ERR_UNSUPPORTED: callers with a documented fallback entry point test for it
 

@@ -1247,14 +1247,15 @@ class BoxBiasFn(torch.autograd.Function):
     """log(clamp(relu(WG(emb(boxes))), 1e-6)) -> [G,heads,N,N] float32 (roi_modeling.py:148-163,40)"""
 
     @staticmethod
-    def forward(ctx, coords, wg_w, wg_b):
+    def forward(ctx, coords, wg_w, wg_b, fast_trig=False):
         c = coords.contiguous()
         H.require_cuda(c, wg_w)
         G, N, _ = c.shape
         heads = wg_w.shape[0]
         ww, wb = wg_w.detach().contiguous().float(), wg_b.detach().contiguous().float()
         bias = torch.empty((G, heads, N, N), dtype=torch.float32, device=c.device)
-        H.check(H.lib().fcmf_box_bias_fwd(H.ptr(c), H.dt(c), H.ptr(box_dim_mat(c.device)), H.ptr(ww), H.ptr(wb),
+        ctx.cdt = H.dt(c) | (H.BOX_FAST_TRIG if fast_trig and c.dtype == torch.float32 else 0)
+        H.check(H.lib().fcmf_box_bias_fwd(H.ptr(c), ctx.cdt, H.ptr(box_dim_mat(c.device)), H.ptr(ww), H.ptr(wb),
                                           H.ptr(bias), G, N, heads, H.stream()), "fcmf_box_bias_fwd")
         ctx.save_for_backward(c, ww, wb)
         return bias
@@ -1267,9 +1268,9 @@ class BoxBiasFn(torch.autograd.Function):
         buf = torch.zeros(ww.numel() + wb.numel(), dtype=torch.float32, device=ww.device)       # (one fill for both)
         dw, db = buf[:ww.numel()].view_as(ww), buf[ww.numel():].view_as(wb)
         d = dbias.contiguous().float()
-        H.check(H.lib().fcmf_box_bias_bwd(H.ptr(c), H.dt(c), H.ptr(box_dim_mat(c.device)), H.ptr(ww), H.ptr(wb), H.ptr(d),
+        H.check(H.lib().fcmf_box_bias_bwd(H.ptr(c), ctx.cdt, H.ptr(box_dim_mat(c.device)), H.ptr(ww), H.ptr(wb), H.ptr(d),
                                           H.ptr(dw), H.ptr(db), G, N, heads, H.stream()), "fcmf_box_bias_bwd")
-        return None, dw, db
+        return None, dw, db, None
 
 
 def box_bias(coords, wg_w, wg_b):
@@ -1277,9 +1278,12 @@ def box_bias(coords, wg_w, wg_b):
     # roi_modeling.py:79-138) and rounds to float32 (:150).  The parity (fp32) mode keeps that; the bf16 mode
     # runs the float32 instantiation of the same kernels (sincosf instead of f64 sincos: 5x faster, error ~1e-5
     # on a bias that is consumed in bf16).
-    if compute_dtype() == torch.bfloat16 and coords.dtype == torch.float64:
+    # ... and the hardware's sine / cosine (FCMF_BOX_FAST_TRIG: the 64 sincosf calls per box pair were two thirds of both kernels;
+    # argument error <= 1e-4 on a bias whose bf16 rounding is 3e-2).
+    bf16_mode = compute_dtype() == torch.bfloat16
+    if bf16_mode and coords.dtype == torch.float64:
         coords = coords.float()
-    return BoxBiasFn.apply(coords, wg_w, wg_b)
+    return BoxBiasFn.apply(coords, wg_w, wg_b, bf16_mode)
 
 
 def box_embedding(coords):

@@ -641,6 +641,40 @@ def test_box_bias(dev, cdtype):
     assert rel_err(ww.grad, wr.grad) < gtol and rel_err(wb.grad, br.grad) < gtol
 
 
+def test_box_bias_bf16_mode_fast_trig(dev):
+    """bf16 compute mode: float32 coordinates and the hardware's sine / cosine (FCMF_BOX_FAST_TRIG).  The bias -- which the
+    attention consumes in bf16 (rounding 3e-2 at its typical magnitude) -- stays within 1e-2 of the float64 reference where the
+    pre-activation is not small (2e-3 in the pre-activation everywhere); the WG gradients within 2e-2 when the upstream
+    gradient leaves out the entries next to the clamp (d log x = dx / x: there ANY arithmetic's last digits decide the sum)."""
+    ops, H = _ops()
+    from oracle import fcmf_oracle as O
+    rng = np.random.Generator(np.random.PCG64(5))
+    G, N = 4, 36
+    xs, ys = np.sort(rng.random((G, N, 2)), -1) * 200, np.sort(rng.random((G, N, 2)), -1) * 150
+    c = torch.from_numpy(np.concatenate([xs, ys], -1))
+    c[1, 30:] = 0
+    ref_emb = O.box_relational_embedding(c).float()
+    ww = (0.1 * _rand((8, 64), dev, seed=1) + 0.05).requires_grad_(True)
+    wb = (0.1 * _rand((8,), dev, seed=2)).requires_grad_(True)
+    wr, br = ww.detach().cpu().requires_grad_(True), wb.detach().cpu().requires_grad_(True)
+    pre = torch.einsum("gije,he->ghij", ref_emb, wr) + br.view(1, 8, 1, 1)
+    ref = torch.log(torch.clamp(F.relu(pre), min=1e-6))
+    wgt = _rand(ref.shape, "cpu", seed=3) * (pre.detach() > 0.1)
+    (ref * wgt).sum().backward()
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        bias = ops.box_bias(c.to(dev), ww, wb)
+        (bias * wgt.to(dev)).sum().backward()
+    finally:
+        ops.set_compute_dtype(torch.float32)
+    live = pre > 1e-2
+    assert live.float().mean() > 0.5
+    assert (torch.exp(bias.detach().cpu()[live]) - pre.detach()[live]).abs().max().item() < 2e-3
+    big = pre > 0.2
+    assert (bias.detach().cpu()[big] - ref.detach()[big]).abs().max().item() < 1e-2
+    assert rel_err(ww.grad, wr.grad) < 2e-2 and rel_err(wb.grad, br.grad) < 2e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cross_entropy(dev, dtype):
     ops, H = _ops()
