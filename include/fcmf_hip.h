@@ -226,6 +226,11 @@ int fcmf_embed_bwd(const void* dz, const int64_t* ids, const int64_t* pos, const
  * into dpos), summed per sequence offset in registers first -- the offsets of all sequences share position rows. */
 int fcmf_embed_pos_bwd(const void* dz, const int64_t* pos, float* dpos, int nseq, int S, int H, int pad_id,
                        int dtype, void* stream);
+/* the position-table AND the type-table gradient (both ACCUMULATED) of tokens laid out [nseq, S] in one pass over dz; call
+ * fcmf_embed_bwd with dpos = dtype_table = NULL beside it.  FCMF_ERR_UNSUPPORTED (H not a multiple of 16 bytes of columns or
+ * more than 256 such groups, unaligned dz): use fcmf_embed_bwd's type-table path + fcmf_embed_pos_bwd. */
+int fcmf_embed_pos_type_bwd(const void* dz, const int64_t* pos, const int64_t* type_ids, float* dpos,
+                            float* dtype_table, int nseq, int S, int H, int pad_id, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Box geometry (roi_modeling.py:79-138,161-163 and the log-clamp of :40), fused:

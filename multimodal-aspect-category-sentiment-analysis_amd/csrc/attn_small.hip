@@ -569,11 +569,12 @@ __global__ __launch_bounds__(256) void attn_private_grad_kernel(AttnK P) {
   const int d = a.d, T2 = a.T2, gd = a.group_div, heads = a.heads, HD = heads * d;
   const int g2 = blockIdx.x / a.R, r = blockIdx.x % a.R;
   const int tb = (T2 + gridDim.y - 1) / gridDim.y, t_lo = blockIdx.y * tb, t_hi = min(T2, t_lo + tb);   // this block's keys
-  float* PD = sm;                          // [gd][heads][T2]
-  float* DS = sm + gd * heads * T2;
-  for (int i = threadIdx.x; i < gd * heads * T2; i += 256) {
-    const int t2 = i % T2, ah = i / T2, hh = ah % heads, aa = ah / heads;
-    const int64_t src = ((((int64_t)g2 * gd + aa) * heads + hh) * a.R + r) * T2 + t2;
+  const int nt = t_hi - t_lo;              // this block's keys only (every block staged all T2 keys of the group: 4x the gather)
+  float* PD = sm;                          // [gd][heads][nt]
+  float* DS = sm + gd * heads * tb;
+  for (int i = threadIdx.x; i < gd * heads * nt; i += 256) {
+    const int tl = i % nt, ah = i / nt, hh = ah % heads, aa = ah / heads;
+    const int64_t src = ((((int64_t)g2 * gd + aa) * heads + hh) * a.R + r) * T2 + t_lo + tl;
     PD[i] = P.pd2[src];
     DS[i] = P.ds2[src];
   }
@@ -600,8 +601,8 @@ __global__ __launch_bounds__(256) void attn_private_grad_kernel(AttnK P) {
 #pragma unroll
       for (int aa = 0; aa < 8; ++aa)
         if (aa < gd) {
-          kacc += DS[(aa * heads + hh) * T2 + t2] * qv[aa];
-          vacc += PD[(aa * heads + hh) * T2 + t2] * ov[aa];
+          kacc += DS[(aa * heads + hh) * nt + t2 - t_lo] * qv[aa];
+          vacc += PD[(aa * heads + hh) * nt + t2 - t_lo] * ov[aa];
         }
       dK2[out0 + (int64_t)t2 * HD] = from_f32<TT>(kacc);
       dV2[out0 + (int64_t)t2 * HD] = from_f32<TT>(vacc);

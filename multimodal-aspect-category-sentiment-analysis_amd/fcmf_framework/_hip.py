@@ -62,6 +62,7 @@ SIGNATURES = {
     "fcmf_embed_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _i, _vp],
     "fcmf_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fcmf_embed_pos_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "fcmf_embed_pos_type_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "fcmf_box_bias_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "fcmf_box_bias_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "fcmf_box_embedding": [_vp, _i, _vp, _vp, _i, _i, _vp],

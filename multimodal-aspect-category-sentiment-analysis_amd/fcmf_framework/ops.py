@@ -1069,9 +1069,17 @@ class EmbedLNFn(torch.autograd.Function):
         dpos = alloc_grad(ptab, ps) if ptab is not None else zeros(ps)
         dtt = alloc_grad(ttab, ts) if ttab is not None else zeros(ts)
         two_d = ids.dim() == 2 and pos.is_contiguous()
+        fused = False
+        if two_d and (tt is None or tt.is_contiguous()):
+            # [sequences, S] layout: position rows are shared by the offsets of all sequences; position and type gradients in ONE pass
+            rc = L.fcmf_embed_pos_type_bwd(H.ptr(dz), H.ptr(pos), H.ptr(tt), H.ptr(dpos), H.ptr(dtt), ids.shape[0], ids.shape[1], Hd,
+                                           ctx.pad_id, H.dt(dz), H.stream())
+            fused = rc == 0
+            if rc not in (0, H.ERR_UNSUPPORTED):
+                H.check(rc, "fcmf_embed_pos_type_bwd")
         H.check(L.fcmf_embed_bwd(H.ptr(dz), H.ptr(ids), H.ptr(pos), H.ptr(tt), H.ptr(dwordbuf), None if two_d else H.ptr(dpos),
-                                 H.ptr(dtt), ntok, Hd, ctx.pad_id, H.dt(dz), H.stream()), "fcmf_embed_bwd")
-        if two_d:      # [sequences, S] layout: position rows are shared by the offsets of all sequences
+                                 None if fused else H.ptr(dtt), ntok, Hd, ctx.pad_id, H.dt(dz), H.stream()), "fcmf_embed_bwd")
+        if two_d and not fused:
             H.check(L.fcmf_embed_pos_bwd(H.ptr(dz), H.ptr(pos), H.ptr(dpos), ids.shape[0], ids.shape[1], Hd, ctx.pad_id,
                                          H.dt(dz), H.stream()), "fcmf_embed_pos_bwd")
         return None, None, None, dword, dpos, dtt, dg, db, None, None, None, None, None

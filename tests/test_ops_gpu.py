@@ -581,9 +581,10 @@ def test_add_layer_norm_dropout(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_embedding_layer_norm(dev, dtype):
+@pytest.mark.parametrize("B,S,H_", [(4, 12, 64), (70, 9, 768), (5, 12, 36)])      # (70 sequences: two sequence groups of the fused
+def test_embedding_layer_norm(dev, dtype, B, S, H_):                              #  position + type gradient kernel; H 36: its fallback)
     ops, H = _ops()
-    V, Pn, H_, B, S, pad = 50, 40, 64, 4, 12, 1
+    V, Pn, pad = 50, 40, 1
     ids = torch.randint(3, V, (B, S), generator=torch.Generator().manual_seed(1))
     ids[0, 7:] = pad
     ids[2, 3:] = pad
