@@ -427,6 +427,10 @@ ATTN_CASES = [
     (2, 30, 2, 96, 100, 0, 1, True, True, False),     # few rows, > 64 keys
     (2, 100, 2, 96, 30, 0, 1, False, True, False),    # > 64 rows, few keys
     (2, 129, 2, 64, 64, 0, 1, True, False, False),    # one row more than the wide limit: the general kernel
+    (2, 16, 2, 128, 100, 20, 1, True, False, False),  # the flat few-rows kernels at their row limit, heads of 128, ungrouped private keys
+    (3, 1, 2, 64, 0, 2, 1, False, False, False),      # ... one row, two private keys
+    (6, 2, 4, 32, 17, 3, 3, True, False, False),      # ... groups of 3, odd key counts
+    (2, 17, 2, 64, 100, 20, 1, True, False, False),   # one row more: the general kernels
 ]
 
 
@@ -489,6 +493,31 @@ def test_attention_expanded_query_rows_read_in_place(dev, dtype):
         res.append((out.detach(), qa.grad, ka.grad, va.grad))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_attention_few_rows_dropout_consistent(dev):
+    """the flat few-rows kernels (bf16, R <= 16, shared + private keys): with V = I split over the two segments the output IS the
+    dropped probability matrix; kept entries are the plain probabilities / (1 - p), and the backward regenerates the same mask
+    (dV1 = P_drop[:, :T1]^T dO, dV2 = P_drop[:, T1:] per row)"""
+    ops, H = _ops()
+    G, R, T1, T2, p = 5, 7, 32, 32, 0.3
+    d = T1 + T2
+    eye = torch.eye(d, device=dev, dtype=torch.bfloat16)
+    q = _rand((G, R, d), dev, torch.bfloat16, seed=1)
+    k1 = _rand((G, T1, d), dev, torch.bfloat16, seed=2)
+    k2 = _rand((G, R, T2, d), dev, torch.bfloat16, seed=3)
+    v1 = eye[:T1].expand(G, T1, d).contiguous().requires_grad_(True)
+    v2 = eye[T1:].expand(G, R, T2, d).contiguous().requires_grad_(True)
+    ops.manual_seed(77)
+    out = ops.attention(q, k1, v1, k2, v2, heads=1, p=p, training=True)
+    plain = ops.attention(q, k1, v1, k2, v2, heads=1, p=0.0, training=False)
+    pdrop, pfull = out.detach().float(), plain.detach().float()
+    kept = pdrop != 0
+    assert 0.55 < kept.float().mean().item() < 0.85
+    assert torch.allclose(pdrop[kept], pfull[kept] / (1 - p), rtol=2e-2, atol=1e-3)
+    out.sum().backward()                                   # dO = 1
+    assert torch.allclose(v1.grad.float()[:, :, 0], pdrop[:, :, :T1].sum(1), rtol=2e-2, atol=2e-2)
+    assert torch.allclose(v2.grad.float()[:, :, :, 0], pdrop[:, :, T1:], rtol=2e-2, atol=2e-2)
 
 
 @pytest.mark.parametrize("R,T", [(16, 16), (100, 104), (128, 128)])
