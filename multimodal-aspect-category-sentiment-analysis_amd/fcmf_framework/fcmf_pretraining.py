@@ -62,11 +62,12 @@ class FCMFEncoder(nn.Module):
 
         # 1. text encoder on all B*A sequences at once                      (fcmf_pretraining.py:41)
         seq = cell.encode(ids, tt, am)                                                   # [Bt,S,H]
-        cls = seq[:, 0]                                                                  # [Bt,H] view
 
         cross = self.text2img_attention.layer[0]
         mm = self.mm_attention.layer[0]
         csa, msa = cross.attention.self, mm.attention.self
+        # the sequence's three consumers -- text keys / values of the mm layer (:97-124) and the [CLS] row -- as one autograd node
+        Kt, Vt, cls = ops.seq_fan(seq, msa.key.weight, msa.key.bias, msa.value.weight, msa.value.bias)   # [Bt,S,H] x2, [Bt,H]
         eps = mm.output.LayerNorm.variance_epsilon
         p_h, p_a = mm.output.dropout.p, msa.dropout.p
 
@@ -93,8 +94,6 @@ class FCMFEncoder(nn.Module):
         h_feat = ops.linear(t2i, pl.dense.weight, pl.dense.bias, act="tanh")             # [Bt,NI,H]
 
         # 4. text+ROI multimodal layer, live row 0 only                        (:97-124)
-        Kt = ops.linear(seq, msa.key.weight, msa.key.bias)                               # [Bt,S,H]
-        Vt = ops.linear(seq, msa.value.weight, msa.value.bias)
         qm = ops.linear(cls, msa.query.weight, msa.query.bias)
         m_roi = layers.additive_mask(added, S + NR)                                      # (:97-100)
         ctx_m = ops.attention(qm.unsqueeze(1).expand(Bt, NI, H), k1=Kt, v1=Vt, k2=Kr, v2=Vr, mask=m_roi,
