@@ -121,8 +121,13 @@ class GradArena:
         """True if the arena slice starting at `slice_ptr` belongs to a parameter that exactly ONE forward GEMM has used since
         zero(): its weight gradient then has a single producer in this backward pass (ops.deferred_dw may delay it; with two
         producers autograd ADDS their results the moment each Function returns)"""
+        return self.uses(slice_ptr) == 1
+
+    def uses(self, slice_ptr):
+        """forward GEMMs that have used the parameter whose arena slice starts at `slice_ptr` since zero() (0: no such slice, or a
+        parameter whose producers are unknown)"""
         p = self._slice_param.get(slice_ptr)
-        return p is not None and self.fwd_uses.get(p.data_ptr(), 0) == 1
+        return 0 if p is None else self.fwd_uses.get(p.data_ptr(), 0)
 
     def take(self, param):
         """the slice of `param` if nothing has claimed it in this step (else None: the caller uses a temporary and

@@ -448,11 +448,16 @@ class _DeferredDW:
                 and C.dtype == torch.float32 and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16):
             return False
         arena = _grad_arena
-        # ... into a slice of the arena that belongs to a parameter with ONE use in this step's forward (a weight that is applied
-        # twice -- the fusion layer runs 7 + 1 times -- has two gradient producers, and autograd adds their results as soon as
-        # each Function returns: neither may be late)
-        return (arena is not None and C.device == arena.flat.device
-                and C.untyped_storage().data_ptr() == arena.flat.untyped_storage().data_ptr() and arena.used_once(C.data_ptr()))
+        if not (arena is not None and C.device == arena.flat.device
+                and C.untyped_storage().data_ptr() == arena.flat.untyped_storage().data_ptr()):
+            return False
+        # A weight applied SEVERAL times (the mm layer's key / value weights: text keys, ROI keys, the fusion layer) has several
+        # producers, but since round 4 every one of them accumulates in place into the slice the first one claimed and hands
+        # autograd None (alloc_grad_ex / GradArena.retake): nothing is added by the engine, so they may all wait for the flush and
+        # batch with the same-shape gradients of the text encoder.  (A destination outside the arena -- the temporaries of a
+        # gradient-accumulation micro-step -- never gets here.)
+        n = arena.uses(C.data_ptr())
+        return n == 1 or (n > 1 and DEFER_SHARED_DW)
 
     def push(self, A, B, C, M, N, K, lda, ldb, ldc, acc):
         if not self.armed:
@@ -528,6 +533,10 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, ta, tb, bias=None, aux=None, epi=H.EPI
         _gemm_trace.append((H.lib().fcmf_gemm_ctx_last_kernel(ctx).decode(), 2.0 * M * N * K, e0, e1))
 
 
+# (see _DeferredDW.wanted; measured on one box, 20 steps, twice each: 36.76 / 36.85 ms off, 36.70 / 36.67 ms on -- 168 instead of 176 GEMM
+#  launches, 26.43 instead of 26.70 ms of GEMM time -- but the batched kernel then also runs the small shared-weight batches and its
+#  per-launch average drops from 1223 to 1194 TFLOP/s.  Off by default: the two configurations are within the box-to-box spread)
+DEFER_SHARED_DW = os.environ.get("FCMF_DEFER_SHARED_DW", "0") == "1"
 HEAD_WGRAD_DIRECT = os.environ.get("FCMF_HEAD_WGRAD_DIRECT", "1") == "1"      # (A/B switch)
 
 
