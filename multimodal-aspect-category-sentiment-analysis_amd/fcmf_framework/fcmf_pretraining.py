@@ -74,13 +74,11 @@ class FCMFEncoder(nn.Module):
         # 2. aspect-independent image side, hoisted out of the aspect loop     (:49-50, :102-111)
         vis = layers.to_compute(visual_embeds_att[:, :NI]).reshape(B * NI * P, -1)
         img = ops.linear(vis, self.vismap2text.weight, self.vismap2text.bias)            # [B*NI*P,H]
-        Kc = ops.linear(img, csa.key.weight, csa.key.bias).view(B, NI, P, H)
-        Vc = ops.linear(img, csa.value.weight, csa.value.bias).view(B, NI, P, H)
+        Kc, Vc = (t.view(B, NI, P, H) for t in ops.linear_multi(img, csa.key.weight, csa.key.bias, csa.value.weight, csa.value.bias))
         roi = layers.to_compute(roi_embeds_att[:, :NI]).reshape(B * NI * NR, -1)
         roi_p = ops.linear(roi, self.roimap2text.weight, self.roimap2text.bias).view(B * NI, NR, H)
         rel = self.box_head(roi_p, roi_p, roi_p, roi_coors[:, :NI].reshape(B * NI, NR, 4))  # [B*NI,NR,H]
-        Kr = ops.linear(rel, msa.key.weight, msa.key.bias).view(B, NI, NR, H)
-        Vr = ops.linear(rel, msa.value.weight, msa.value.bias).view(B, NI, NR, H)
+        Kr, Vr = (t.view(B, NI, NR, H) for t in ops.linear_multi(rel, msa.key.weight, msa.key.bias, msa.value.weight, msa.value.bias))
 
         cls_rep = cls.unsqueeze(1).expand(Bt, NI, H)
 

@@ -772,6 +772,44 @@ class SeqFanFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2
 
 
+class MultiLinearFn(torch.autograd.Function):
+    """several nn.Linear on the SAME input (q / k / v of the box attention on the ROI features, roi_modeling.py:170-173; key / value
+    of the cross attention on the patch features) as one autograd node: the input gradient is accumulated by the dX GEMMs' add
+    epilogue instead of n - 1 full-size adds by the engine.  Arguments: x, w1, b1, w2, b2, ...; returns one output per pair."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        x2 = _rows(x)
+        ws, bs = wb[0::2], wb[1::2]
+        ys = tuple(_linear_fwd(x2, as_compute(w, x2.dtype), None if b is None else b.detach(), master=w) for w, b in zip(ws, bs))
+        ctx.save_for_backward(x2, *ws)
+        ctx.biases = bs
+        ctx.xshape = x.shape
+        return tuple(y.view(*x.shape[:-1], w.shape[0]) for y, w in zip(ys, ws))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2, *ws = ctx.saved_tensors
+        need_dx = ctx.needs_input_grad[0]
+        dx = None
+        grads = []
+        for i, (dy, w, b) in enumerate(zip(dys, ws, ctx.biases)):
+            if dy is None:
+                grads += [None, None]
+                continue
+            d = dy.reshape(-1, dy.shape[-1]).contiguous()
+            dx, dw, db = _linear_bwd(x2, as_compute(w, x2.dtype), d, need_dx, ctx.needs_input_grad[1 + 2 * i],
+                                     b is not None and ctx.needs_input_grad[2 + 2 * i],
+                                     dx_epi=H.EPI_NONE if dx is None else H.EPI_ADD, dx_aux=dx, master=w, bias_param=b)
+            grads += [dw, db]
+        return (None if dx is None else dx.view(ctx.xshape), *grads)
+
+
+def linear_multi(x, *wb):
+    """(x W1^T + b1, x W2^T + b2, ...) with ONE gradient tensor for x (see MultiLinearFn)"""
+    return MultiLinearFn.apply(x, *wb)
+
+
 def seq_fan(seq, w1, b1, w2, b2):
     """-> (seq W1^T + b1, seq W2^T + b2, seq[:, 0]) with ONE gradient tensor for `seq` (see SeqFanFn)"""
     return SeqFanFn.apply(seq, w1, b1, w2, b2)

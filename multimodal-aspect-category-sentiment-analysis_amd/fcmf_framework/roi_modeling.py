@@ -71,9 +71,13 @@ class BoxMultiHeadedAttention(nn.Module):
             raise NotImplementedError("BoxMultiHeadedAttention is only called with mask=None")
         q_in, k_in, v_in = (layers.to_compute(t) for t in (input_query, input_key, input_value))
         bias = self.geometry_bias(input_box)
-        q = ops.linear(q_in, self.linears[0].weight, self.linears[0].bias)
-        k = ops.linear(k_in, self.linears[1].weight, self.linears[1].bias)
-        v = ops.linear(v_in, self.linears[2].weight, self.linears[2].bias)
+        if input_query is input_key and input_key is input_value:      # (the only way FCMF calls it, fcmf_pretraining.py:108)
+            q, k, v = ops.linear_multi(q_in, self.linears[0].weight, self.linears[0].bias, self.linears[1].weight, self.linears[1].bias,
+                                       self.linears[2].weight, self.linears[2].bias)
+        else:
+            q = ops.linear(q_in, self.linears[0].weight, self.linears[0].bias)
+            k = ops.linear(k_in, self.linears[1].weight, self.linears[1].bias)
+            v = ops.linear(v_in, self.linears[2].weight, self.linears[2].bias)
         x = ops.attention(q, k1=k, v1=v, bias=bias, heads=self.h, scale=1.0 / math.sqrt(self.d_k),
                           p=self.dropout.p, training=self.training)
         if self.legacy_extra_skip:
