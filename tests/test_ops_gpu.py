@@ -842,6 +842,39 @@ def test_linear_and_ffn_autograd(dev, dtype):
         assert rel_err(a.grad, r.grad) < tol * 2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shared_input_projections_as_one_node(dev, dtype):
+    """ops.linear_multi (q / k / v of the box attention, key / value pairs on one input) and ops.seq_fan (key / value projections +
+    the [CLS] row of the text encoder's output): outputs and every gradient equal the separate nn.Linear / slicing graph
+    (roi_modeling.py:170-173, fcmf_pretraining.py:97-124) -- the input gradient is accumulated by the dX GEMMs' add epilogue,
+    the [CLS] gradient lands in row 0; a weight shared between two projections accumulates in place; an unused output is fine"""
+    ops, H = _ops()
+    G, S, Hd = 6, 10, 64
+    x = _rand((G, S, Hd), dev, dtype, seed=1).requires_grad_(True)
+    ws = [_rand((Hd, Hd), dev, scale=0.2, seed=2 + i).requires_grad_(True) for i in range(3)]
+    bs = [_rand((Hd,), dev, seed=7 + i).requires_grad_(True) for i in range(3)]
+    wg = [_rand((G, S, Hd), dev, seed=20 + i) for i in range(3)]
+    wc = _rand((G, Hd), dev, seed=30)
+    q, k, v = ops.linear_multi(x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2])
+    k2, v2, cls = ops.seq_fan(x, ws[1], bs[1], ws[2], None)                 # (weights 1 and 2 used a second time; one without bias)
+    loss = sum((t.float() * w_).sum() for t, w_ in zip((q, k, v), wg)) + (k2.float() * wg[0]).sum() + (cls.float() * wc).sum()
+    loss.backward()                                                          # (v2 unused: its gradient arrives as None)
+    xr = x.detach().float().cpu().requires_grad_(True)
+    wr = [w.detach().cpu().requires_grad_(True) for w in ws]
+    br = [b.detach().cpu().requires_grad_(True) for b in bs]
+    wcast = (lambda w: w) if dtype == torch.float32 else (lambda w: w.bfloat16().float())
+    qr, kr, vr = (F.linear(xr, wcast(wr[i]), br[i]) for i in range(3))
+    k2r = F.linear(xr, wcast(wr[1]), br[1])
+    ref = sum((t * w_.cpu()).sum() for t, w_ in zip((qr, kr, vr), wg)) + (k2r * wg[0].cpu()).sum() + (xr[:, 0] * wc.cpu()).sum()
+    ref.backward()
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    for a, r in ((q, qr), (k, kr), (v, vr), (k2, k2r), (v2, F.linear(xr, wcast(wr[2]))), (cls, xr[:, 0])):
+        assert rel_err(a, r) < tol
+    assert rel_err(x.grad, xr.grad) < tol * 2
+    for a, r in zip(ws + bs, wr + br):
+        assert rel_err(a.grad, r.grad) < tol * 2
+
+
 def test_fused_adamw_matches_torch(dev):
     """clip_grad_norm_(1.0) + torch.optim.AdamW (run_multimodal_fcmf.py:485-487) in two kernels"""
     from fcmf_framework.optimization import FusedAdamW
