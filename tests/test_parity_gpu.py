@@ -11,6 +11,7 @@ Tolerances
               cosine >= 0.999 on the fixture's sampled elements and against the full fp32 gradient.
               Measured on MI355X: see the numbers next to each bound.
 """
+import math
 import os
 
 import numpy as np
@@ -1101,3 +1102,39 @@ def test_deferred_weight_gradients_equal_immediate_ones_bf16(base, dev):
         ops.set_grad_arena(old_arena)
         _set(torch.float32)
         model.zero_grad(set_to_none=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_memorises_a_fixed_batch(dev, dtype):
+    """end to end, many steps: the benchmarked training graph (dropout on, gradient arena, deferred + batched weight gradients,
+    fused clip + AdamW) on ONE fixed batch of the tiny geometry -- the loss starts at 6 ln 4 (six aspects, four classes, random
+    head) and must fall well below it; every parameter stays finite.  (Single-step parity against the reference is pinned above;
+    this guards the composition over steps: stale shadows, arena reuse, in-place shared-weight gradients.)"""
+    from fcmf_framework import ops
+    from fcmf_framework.dp import GradArena
+    from fcmf_framework.optimization import FusedAdamW
+    NI, NR, B, S = 2, 5, 8, 16
+    old = ops.grad_arena()
+    _set(dtype)
+    try:
+        model, _ = build_fcmf(synth.TINY_CFG, NI, NR, dev)
+        model.train()
+        ops.manual_seed(5)
+        batch = batch_to(synth.synth_batch(B, synth.TINY_CFG, S=S, num_imgs=NI, num_roi=NR, seed=3), dev)
+        arena = GradArena.for_model(model)
+        opt = FusedAdamW([p for p in model.parameters()], lr=2e-3, weight_decay=0.0)
+        losses = []
+        for _ in range(60):
+            arena.zero()
+            loss = model.loss_aspects(_run_aspects(model, batch), batch["labels"])
+            loss.backward()
+            opt.step(max_grad_norm=1.0)
+            losses.append(loss.item())
+        assert abs(losses[0] - 6 * math.log(4)) < 1.5, losses[0]
+        assert min(losses[-5:]) < 0.35 * losses[0], (losses[0], losses[-5:])
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+    finally:
+        if "arena" in locals():
+            arena.deactivate()
+        ops.set_grad_arena(old)
+        _set(torch.float32)
